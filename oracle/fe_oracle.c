@@ -1,0 +1,392 @@
+/*
+ * fe_oracle.c -- CPU restatement of the reference's TimeSeriesEnv hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle: a scalar, plain-C
+ * restatement of hmomin/FinEnvs finenvs/environments/time_series_env.py
+ * (abbreviated TSE below).  Only tests/, __graft_entry__.smoke() and the
+ * cpu_baseline leg of bench.py may load it.  The product (finenvs_amd/) never
+ * links, imports or calls anything in oracle/; it has no CPU fallback.
+ *
+ * Parity is PINNED: tests/test_oracle_golden.py checks every function here
+ * bit-for-bit against fixtures under tests/golden/ that were produced by
+ * running the reference itself in the build container
+ * (oracle/make_goldens.py is the generating script).
+ *
+ * Every (float)/(double) cast below is a real rounding point of the
+ * reference's mixed f32/f64 tensor arithmetic; build with -ffp-contract=off.
+ *
+ * Multi-asset (A > 1) has no reference: it is the "sleeve" contract of
+ * DESIGN.md -- each (env, asset) pair is one independent reference account on
+ * a shared calendar; reward = sum over assets in asset order; done = OR.
+ * With A == 1 every formula below is exactly the reference's.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct fo_config {
+    int64_t N, D, L;          /* envs, days, padded day length            */
+    int32_t W, A;             /* window (num_intervals), assets           */
+    int32_t max_shares;       /* TSE:20                                   */
+    int32_t evaluate;         /* TSE:27                                   */
+    double starting_balance;  /* TSE:21                                   */
+    double commission;        /* TSE:22                                   */
+    double init_margin;       /* TSE:25                                   */
+    double maint_margin;      /* TSE:26                                   */
+    int32_t obs_is_f32;       /* build extension: observation dtype       */
+    int32_t redraw_mode;      /* 0 host (torch RNG), 1 device Philox      */
+    uint64_t seed;            /* Philox key for redraw_mode 1             */
+    int64_t eval_env;         /* index of the training-mode eval env, -1  */
+} fo_config;
+
+/* ---- Philox4x32-10 (Salmon et al. 2011), the device redraw generator ---- */
+static inline void philox_round(uint32_t c[4], const uint32_t k[2]) {
+    uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k[0];
+    uint32_t n1 = (uint32_t)p1;
+    uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k[1];
+    uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+
+uint32_t fo_philox_u32(uint64_t seed, uint64_t counter) {
+    uint32_t c[4] = {(uint32_t)counter, (uint32_t)(counter >> 32), 0x46454e56u, 0u};
+    uint32_t k[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k);
+        k[0] += 0x9E3779B9u;
+        k[1] += 0xBB67AE85u;
+    }
+    return c[0];
+}
+
+int64_t fo_redraw_day(uint64_t seed, uint64_t counter, int64_t D) {
+    return (int64_t)(((uint64_t)fo_philox_u32(seed, counter) * (uint64_t)D) >> 32);
+}
+
+/* ---- a18: log-return transform over the whole filtered series, TSE:179-194 ---- */
+void fo_build_logret(const double *prices, double *out, int64_t T, int32_t A) {
+    const int64_t stride = 4 * (int64_t)A;
+    for (int64_t t = 0; t < T; ++t) {
+        for (int32_t a = 0; a < A; ++a) {
+            const double *p = prices + t * stride + 4 * a;
+            double *o = out + t * stride + 4 * a;
+            double open = p[0];
+            /* previous close; the first row uses its own open (TSE:188-190) */
+            double prev = (t == 0) ? open : prices[(t - 1) * stride + 4 * a + 3];
+            o[0] = 100.0 * log(open / prev);
+            for (int k = 1; k < 4; ++k) o[k] = 100.0 * log(p[k] / open);
+        }
+    }
+}
+
+/* ---- a19: per-day slices [start, stop], NaN-padded to L, TSE:196-216 ---- */
+void fo_build_tables(const double *series, int64_t T, int32_t A, const int64_t *starts,
+                     const int64_t *stops, int64_t D, int64_t L, double *out) {
+    const int64_t stride = 4 * (int64_t)A;
+    (void)T;
+    for (int64_t d = 0; d < D; ++d) {
+        int64_t len = stops[d] - starts[d] + 1;
+        for (int64_t r = 0; r < L; ++r) {
+            double *o = out + (d * L + r) * stride;
+            if (r < len) {
+                memcpy(o, series + (starts[d] + r) * stride, (size_t)stride * sizeof(double));
+            } else {
+                for (int64_t k = 0; k < stride; ++k) o[k] = NAN;
+            }
+        }
+    }
+}
+
+/* ---- a20: episode bounds, TSE:127-152.  day_id is the per-row date label of the
+ * market-hours-filtered frame, in file order. ---- */
+int64_t fo_bounds(const int64_t *day_id, int64_t T, int32_t W, int64_t *starts, int64_t *stops,
+                  int64_t *max_length) {
+    int64_t D = 0, maxlen = 0, t = 0;
+    while (t < T) {
+        int64_t first = t, d = day_id[t];
+        while (t < T && day_id[t] == d) ++t;
+        int64_t last = t - 1;
+        int64_t start = first - W; /* backtrack by the window, TSE:151 */
+        if (start < 0) continue;   /* TSE:134-135 */
+        if (last - start + 1 > maxlen) maxlen = last - start + 1;
+        starts[D] = start;
+        stops[D] = last;
+        ++D;
+    }
+    *max_length = maxlen;
+    return D;
+}
+
+#define FO_MAX_ASSETS 256
+
+/* ---- a3: TSE:298-302 ---- */
+static inline float share_change(const fo_config *c, float action) {
+    float scaled = action * (float)((double)c->max_shares + 0.5);
+    float sc = rintf(scaled); /* round-half-even, as torch.round */
+    float ms = (float)c->max_shares;
+    if (sc < -ms) sc = -ms;
+    if (sc > ms) sc = ms;
+    return sc;
+}
+
+typedef struct sleeve_out {
+    double pos_obs;  /* position feature of the observation  */
+    double rew;      /* reward before the liquidation fee    */
+    int bankrupt;    /* cash < 0 anywhere in the reward step */
+} sleeve_out;
+
+/* one (env, asset) account: steps 1-6 of SURVEY Appendix A */
+static inline void sleeve_step(const fo_config *c, float action, const double bar[4], float *cash_io,
+                               float *long_io, float *short_io, double *margin_io, sleeve_out *out) {
+    const double O = bar[0], H = bar[1], Lo = bar[2], C = bar[3];
+    const double comm_d = c->commission;
+    const float c32 = (float)c->commission;
+    const double imr = c->init_margin;
+    const float imr32 = (float)c->init_margin;
+    const double one_mmr = 1.0 + c->maint_margin;
+    float cash = *cash_io, lng = *long_io, sht = *short_io;
+    double margin = *margin_io;
+    float comm = 0.0f; /* TSE:305 */
+
+    float sc = share_change(c, action);
+    float pos = sc < 0.0f ? 0.0f : sc; /* TSE:344-351 */
+    float neg = sc > 0.0f ? 0.0f : sc;
+
+    /* 1 sell long, TSE:353-361 */
+    float nl = lng + neg;
+    nl = nl > 0.0f ? nl : 0.0f;
+    float sell = lng - nl;
+    neg += sell;
+    comm += sell * c32;
+    cash = (float)((double)cash + (double)sell * (O - comm_d));
+    lng = nl;
+
+    /* 2 buy back short, TSE:367-383 */
+    float ns = sht - pos;
+    ns = ns > 0.0f ? ns : 0.0f;
+    float bb = sht - ns;
+    pos -= bb;
+    comm += bb * c32;
+    cash = (float)((double)cash - (double)bb * (O + comm_d));
+    sht = ns;
+    double nm = (double)(imr32 * sht) * O;
+    cash = (float)((double)cash - (nm - margin));
+    margin = nm;
+
+    /* 3 long entry, TSE:385-399 */
+    if ((double)cash - (double)pos * (O + comm_d) < 0.0) pos = 0.0f;
+    comm += pos * c32;
+    cash = (float)((double)cash - (double)pos * (O + comm_d));
+    lng += pos;
+
+    /* 4 short entry, TSE:401-421 */
+    float q = -neg;
+    if (((double)cash - imr * ((double)q * O)) - (double)(q * c32) < 0.0) {
+        neg = 0.0f;
+        q = -neg;
+    }
+    comm += q * c32;
+    double req = imr * ((double)q * O);
+    cash = (float)((double)cash - (req + (double)(q * c32)));
+    margin += req;
+    sht += q;
+
+    /* 5 observation feature, rendered post-trade, TSE:428-431 */
+    out->pos_obs = (double)(lng - sht) * C / c->starting_balance;
+
+    /* 6 reward, TSE:447-475 */
+    int done = cash < 0.0f;
+    double rew;
+    {   /* maintenance margin check at the High */
+        double call = (double)sht * H * one_mmr - margin;
+        call = call > 0.0 ? call : 0.0;
+        cash = (float)((double)cash - call);
+        margin += call;
+        done |= cash < 0.0f;
+        rew = -call;
+    }
+    {   /* margin release at the Low */
+        double rel = margin - (double)sht * Lo * imr;
+        rel = rel > 0.0 ? rel : 0.0;
+        margin -= rel;
+        cash = (float)((double)cash + rel);
+    }
+    {   /* maintenance margin check at the Close */
+        double call = (double)sht * C * one_mmr - margin;
+        call = call > 0.0 ? call : 0.0;
+        cash = (float)((double)cash - call);
+        margin += call;
+        done |= cash < 0.0f;
+        rew += -call;
+    }
+    if (done) { lng = 0.0f; sht = 0.0f; }
+    rew += (double)(lng - sht) * (C - O);
+    rew -= (double)comm;
+
+    *cash_io = cash; *long_io = lng; *short_io = sht; *margin_io = margin;
+    out->rew = rew;
+    out->bankrupt = done;
+}
+
+/*
+ * a2: one step() of all N envs, TSE:277-296.
+ *
+ * State (all host pointers): env_idx (N) i64, spot0 (N) i64 (first window
+ * row; env_spots[n][j] == spot0[n]+j and env_pointers == spot0 in the
+ * reference), cash/long/short (N*A) f32, margin (N*A) f64.
+ * Evaluate-mode state (may be NULL unless cfg->evaluate): terminated (N) u8,
+ * episode_returns (N) f32, n_terminated (1) i64.
+ * redraw_counter (1) u64 is used by redraw_mode 1 only.
+ * obs is (N, W, 5A) f64 (or f32 when cfg->obs_is_f32).
+ */
+int fo_step(const fo_config *c, const double *P, const double *LR, int64_t *env_idx, int64_t *spot0,
+            float *cash, float *lng, float *sht, double *margin, uint8_t *terminated,
+            float *episode_returns, int64_t *n_terminated, uint64_t *redraw_counter,
+            const float *actions, void *obs, double *rew_out, int32_t *done_out, int nthreads) {
+    const int64_t N = c->N, L = c->L;
+    const int32_t W = c->W, A = c->A;
+    const int64_t rs = 4 * (int64_t)A; /* table row stride in doubles */
+    const float c32 = (float)c->commission;
+    if (A > FO_MAX_ASSETS) return -1;
+    (void)nthreads;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static) num_threads(nthreads > 0 ? nthreads : 1)
+#endif
+    for (int64_t n = 0; n < N; ++n) {
+        double posv[FO_MAX_ASSETS], rewv[FO_MAX_ASSETS];
+        int64_t idx = env_idx[n];
+        int64_t s0 = spot0[n] + 1;          /* TSE:281-282 */
+        int64_t last = s0 + W - 1;          /* env_spots[:, -1] */
+        int64_t nxt = last + 1;             /* TSE:480 */
+        const double *Pd = P + idx * L * rs;
+        const double *LRd = LR + idx * L * rs;
+        int any_done = 0;
+        for (int32_t a = 0; a < A; ++a) {
+            sleeve_out so;
+            sleeve_step(c, actions[n * A + a], Pd + last * rs + 4 * a, &cash[n * A + a],
+                        &lng[n * A + a], &sht[n * A + a], &margin[n * A + a], &so);
+            posv[a] = so.pos_obs;
+            rewv[a] = so.rew;
+            /* 7 termination, TSE:477-496 */
+            int done = so.bankrupt;
+            done |= (nxt >= L);
+            if (!done) done = isnan(LRd[nxt * rs + 4 * a]);
+            any_done |= done;
+        }
+        /* liquidation fee on every sleeve of a finished env, TSE:288-289 */
+        double rew = 0.0;
+        for (int32_t a = 0; a < A; ++a) {
+            float fee = ((any_done ? 1.0f : 0.0f) * (sht[n * A + a] + lng[n * A + a])) * c32;
+            double r = rewv[a] - (double)fee;
+            rew = (a == 0) ? r : rew + r;
+        }
+        /* observation: terminal window + position column, TSE:423-445 */
+        if (c->obs_is_f32) {
+            float *o = (float *)obs + n * (int64_t)W * 5 * A;
+            for (int32_t j = 0; j < W; ++j)
+                for (int32_t a = 0; a < A; ++a) {
+                    const double *src = LRd + (s0 + j) * rs + 4 * a;
+                    float *dst = o + ((int64_t)j * A + a) * 5;
+                    for (int k = 0; k < 4; ++k) dst[k] = (float)src[k];
+                    dst[4] = (float)posv[a];
+                }
+        } else {
+            double *o = (double *)obs + n * (int64_t)W * 5 * A;
+            for (int32_t j = 0; j < W; ++j)
+                for (int32_t a = 0; a < A; ++a) {
+                    const double *src = LRd + (s0 + j) * rs + 4 * a;
+                    double *dst = o + ((int64_t)j * A + a) * 5;
+                    for (int k = 0; k < 4; ++k) dst[k] = src[k];
+                    dst[4] = posv[a];
+                }
+        }
+        /* 8 episodic reset, TSE:498-521 */
+        if (any_done) {
+            for (int32_t a = 0; a < A; ++a) {
+                cash[n * A + a] = (float)c->starting_balance;
+                margin[n * A + a] = 0.0;
+                lng[n * A + a] = 0.0f;
+                sht[n * A + a] = 0.0f;
+            }
+            s0 = 0;
+            if (!c->evaluate && c->redraw_mode == 1 && n == c->eval_env) {
+                /* only one env ever draws, so no race under OpenMP */
+                env_idx[n] = fo_redraw_day(c->seed, *redraw_counter, c->D);
+                *redraw_counter += 1;
+            }
+        }
+        spot0[n] = s0;
+        /* a17 evaluate-mode bookkeeping, TSE:523-536 */
+        if (c->evaluate) {
+            if (terminated[n]) rew = 0.0;
+            if (any_done && !terminated[n]) {
+                terminated[n] = 1;
+#ifdef _OPENMP
+#pragma omp atomic
+#endif
+                *n_terminated += 1;
+            }
+            episode_returns[n] = (float)((double)episode_returns[n] + rew);
+        }
+        rew_out[n] = rew;
+        done_out[n] = any_done;
+    }
+    return 0;
+}
+
+/* a10/a11: reset() only renders the observation of the current state, TSE:423-445 */
+int fo_reset_obs(const fo_config *c, const double *P, const double *LR, const int64_t *env_idx,
+                 const int64_t *spot0, const float *lng, const float *sht, void *obs) {
+    const int64_t N = c->N, L = c->L;
+    const int32_t W = c->W, A = c->A;
+    const int64_t rs = 4 * (int64_t)A;
+    for (int64_t n = 0; n < N; ++n) {
+        int64_t idx = env_idx[n], s0 = spot0[n], last = s0 + W - 1;
+        const double *Pd = P + idx * L * rs;
+        const double *LRd = LR + idx * L * rs;
+        for (int32_t j = 0; j < W; ++j)
+            for (int32_t a = 0; a < A; ++a) {
+                double C = Pd[last * rs + 4 * a + 3];
+                double pos = (double)(lng[n * A + a] - sht[n * A + a]) * C / c->starting_balance;
+                const double *src = LRd + (s0 + j) * rs + 4 * a;
+                if (c->obs_is_f32) {
+                    float *dst = (float *)obs + (n * (int64_t)W * A + (int64_t)j * A + a) * 5;
+                    for (int k = 0; k < 4; ++k) dst[k] = (float)src[k];
+                    dst[4] = (float)pos;
+                } else {
+                    double *dst = (double *)obs + (n * (int64_t)W * A + (int64_t)j * A + a) * 5;
+                    for (int k = 0; k < 4; ++k) dst[k] = src[k];
+                    dst[4] = pos;
+                }
+            }
+    }
+    return 0;
+}
+
+/*
+ * f1: discounted returns over a (T, N) trajectory chunk, the loop of
+ * finenvs/agents/PPO/buffer.py:80-100 with its tensor dtypes spelled out:
+ * rewards f64, dones int32, last_values f32, gamma a Python float.
+ * (1 - dones) * gamma is an int32 tensor times a Python scalar -> f32, so the
+ * discount factor is gamma rounded to f32; the first product (with f32
+ * last_values) is an f32 product, later ones are f64; returns are stored f32.
+ * Layout here is time-major (T, N).
+ */
+void fo_discounted_returns(const double *rew, const int32_t *done, const float *last_values,
+                           int64_t T, int64_t N, double gamma, float *returns_out) {
+    const float g32 = (float)gamma;
+    for (int64_t n = 0; n < N; ++n) {
+        double R = 0.0;
+        for (int64_t t = T - 1; t >= 0; --t) {
+            float factor = (float)(1 - done[t * N + n]) * g32;
+            if (t == T - 1)
+                R = rew[t * N + n] + (double)(factor * last_values[n]);
+            else
+                R = rew[t * N + n] + (double)factor * R;
+            returns_out[t * N + n] = (float)R;
+        }
+    }
+}

@@ -1,0 +1,178 @@
+"""ctypes/numpy front-end of the C parity oracle (oracle/fe_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py -- never by finenvs_amd.  It mirrors the state
+layout of the reference's TimeSeriesEnv (TSE:245-269) in numpy arrays so that
+a test can step the oracle and the HIP env side by side on the same inputs.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libfe_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "fe_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-s", "-C", _HERE, "-B", "libfe_oracle.so"])
+    return _LIB_PATH
+
+
+class FoConfig(C.Structure):
+    _fields_ = [
+        ("N", C.c_int64), ("D", C.c_int64), ("L", C.c_int64),
+        ("W", C.c_int32), ("A", C.c_int32),
+        ("max_shares", C.c_int32), ("evaluate", C.c_int32),
+        ("starting_balance", C.c_double), ("commission", C.c_double),
+        ("init_margin", C.c_double), ("maint_margin", C.c_double),
+        ("obs_is_f32", C.c_int32), ("redraw_mode", C.c_int32),
+        ("seed", C.c_uint64), ("eval_env", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = C.CDLL(build())
+        _lib.fo_redraw_day.restype = C.c_int64
+        _lib.fo_redraw_day.argtypes = [C.c_uint64, C.c_uint64, C.c_int64]
+        _lib.fo_philox_u32.restype = C.c_uint32
+        _lib.fo_philox_u32.argtypes = [C.c_uint64, C.c_uint64]
+        _lib.fo_bounds.restype = C.c_int64
+    return _lib
+
+
+def _p(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+def build_logret(prices: np.ndarray) -> np.ndarray:
+    prices = np.ascontiguousarray(prices, dtype=np.float64)
+    T, c4 = prices.shape
+    out = np.empty_like(prices)
+    lib().fo_build_logret(_p(prices), _p(out), C.c_int64(T), C.c_int32(c4 // 4))
+    return out
+
+
+def bounds(day_id: np.ndarray, W: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    day_id = np.ascontiguousarray(day_id, dtype=np.int64)
+    T = day_id.shape[0]
+    starts = np.empty(T, dtype=np.int64)
+    stops = np.empty(T, dtype=np.int64)
+    maxlen = C.c_int64(0)
+    D = lib().fo_bounds(_p(day_id), C.c_int64(T), C.c_int32(W), _p(starts), _p(stops), C.byref(maxlen))
+    return starts[:D].copy(), stops[:D].copy(), int(maxlen.value)
+
+
+def build_tables(series: np.ndarray, starts: np.ndarray, stops: np.ndarray, L: int) -> np.ndarray:
+    series = np.ascontiguousarray(series, dtype=np.float64)
+    T, c4 = series.shape
+    D = len(starts)
+    out = np.empty((D, L, c4), dtype=np.float64)
+    lib().fo_build_tables(_p(series), C.c_int64(T), C.c_int32(c4 // 4), _p(np.ascontiguousarray(starts, dtype=np.int64)),
+                          _p(np.ascontiguousarray(stops, dtype=np.int64)), C.c_int64(D), C.c_int64(L), _p(out))
+    return out
+
+
+def tables_from_series(prices: np.ndarray, day_id: np.ndarray, W: int):
+    """Market-hours-filtered series -> (price tables, log-return tables, starts, stops, L)."""
+    starts, stops, L = bounds(day_id, W)
+    lr = build_logret(prices)
+    return build_tables(prices, starts, stops, L), build_tables(lr, starts, stops, L), starts, stops, L
+
+
+def discounted_returns(rew: np.ndarray, done: np.ndarray, last_values: np.ndarray, gamma: float) -> np.ndarray:
+    rew = np.ascontiguousarray(rew, dtype=np.float64)
+    done = np.ascontiguousarray(done, dtype=np.int32)
+    last_values = np.ascontiguousarray(last_values, dtype=np.float32)
+    T, N = rew.shape
+    out = np.empty((T, N), dtype=np.float32)
+    lib().fo_discounted_returns(_p(rew), _p(done), _p(last_values), C.c_int64(T), C.c_int64(N), C.c_double(gamma), _p(out))
+    return out
+
+
+class OracleEnv:
+    """numpy-state mirror of TimeSeriesEnv driven by fo_step / fo_reset_obs."""
+
+    def __init__(
+        self,
+        prices: np.ndarray,
+        logret: np.ndarray,
+        num_intervals: int,
+        num_envs: Optional[int] = None,
+        max_shares: int = 5,
+        starting_balance: float = 10000,
+        per_share_commission: float = 0.01,
+        initial_margin_requirement: float = 1.5,
+        maintenance_margin_requirement: float = 0.25,
+        evaluate: bool = False,
+        env_indices: Optional[np.ndarray] = None,
+        obs_f32: bool = False,
+        redraw_mode: int = 0,
+        seed: int = 0,
+        eval_env: Optional[int] = None,
+        nthreads: int = 1,
+    ):
+        self.P = np.ascontiguousarray(prices, dtype=np.float64)
+        self.LR = np.ascontiguousarray(logret, dtype=np.float64)
+        D, L, c4 = self.P.shape
+        A = c4 // 4
+        if env_indices is None:
+            N = num_envs if num_envs is not None else D
+            env_indices = np.arange(N, dtype=np.int64) % D
+        self.env_idx = np.ascontiguousarray(env_indices, dtype=np.int64).copy()
+        N = self.env_idx.shape[0]
+        if eval_env is None:
+            eval_env = -1 if evaluate else N - 1
+        self.cfg = FoConfig(N, D, L, num_intervals, A, max_shares, int(evaluate), float(starting_balance),
+                            float(per_share_commission), float(initial_margin_requirement),
+                            float(maintenance_margin_requirement), int(obs_f32), redraw_mode, seed, eval_env)
+        self.N, self.D, self.L, self.W, self.A = N, D, L, num_intervals, A
+        self.nthreads = nthreads
+        self.spot0 = np.zeros(N, dtype=np.int64)
+        self.cash = np.full((N, A), np.float32(starting_balance), dtype=np.float32)
+        self.long = np.zeros((N, A), dtype=np.float32)
+        self.short = np.zeros((N, A), dtype=np.float32)
+        self.margin = np.zeros((N, A), dtype=np.float64)
+        self.terminated = np.zeros(N, dtype=np.uint8)
+        self.episode_returns = np.zeros(N, dtype=np.float32)
+        self.n_terminated = np.zeros(1, dtype=np.int64)
+        self.redraw_counter = np.zeros(1, dtype=np.uint64)
+        self.obs_dtype = np.float32 if obs_f32 else np.float64
+        self.obs = np.empty((N, self.W, 5 * A), dtype=self.obs_dtype)
+        self.rew = np.empty(N, dtype=np.float64)
+        self.done = np.empty(N, dtype=np.int32)
+
+    def reset(self) -> np.ndarray:
+        lib().fo_reset_obs(C.byref(self.cfg), _p(self.P), _p(self.LR), _p(self.env_idx), _p(self.spot0),
+                           _p(self.long), _p(self.short), _p(self.obs))
+        return self.obs
+
+    def step(self, actions: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Dict]:
+        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
+        rc = lib().fo_step(C.byref(self.cfg), _p(self.P), _p(self.LR), _p(self.env_idx), _p(self.spot0),
+                           _p(self.cash), _p(self.long), _p(self.short), _p(self.margin), _p(self.terminated),
+                           _p(self.episode_returns), _p(self.n_terminated), _p(self.redraw_counter), _p(a),
+                           _p(self.obs), _p(self.rew), _p(self.done), C.c_int(self.nthreads))
+        if rc != 0:
+            raise RuntimeError(f"fo_step failed: {rc}")
+        info: Dict = {}
+        if self.cfg.evaluate and int(self.n_terminated[0]) == self.N:
+            info = {"returns": self.episode_returns.copy()}
+            self.terminated[:] = 0
+            self.episode_returns[:] = 0
+            self.n_terminated[0] = 0
+        return self.obs, self.rew, self.done, info
+
+    def set_day(self, env: int, day: int) -> None:
+        self.env_idx[env] = day
