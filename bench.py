@@ -1,0 +1,216 @@
+#!/usr/bin/env python3
+"""bench.py -- env-steps/s of the fused TimeSeriesEnv.step() hot path on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W] [--config 2|3|4|1] [--no-cpu]
+
+N > 1 is launched by the driver as
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+one rank per GPU; envs are sharded contiguously (weak scaling: every rank owns the
+config's full env count), no collective inside step(); once per TRAJ_T steps the
+compact trajectory fields are all-gathered over RCCL.
+
+A "step" is one env.step(actions) over all envs of the workload: synthetic GBM minute
+bars (65 business days -> D=64 episodes of 390 bars), a ring of 8
+pre-generated uniform action tensors already resident in HBM, training mode, f64
+observations (the reference's dtype).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+CONFIGS = {
+    # BASELINE.json configs: name -> (envs per GPU, assets, window)
+    1: ("1k envs, 1 asset, window=32", 1024, 1, 32),
+    2: ("64k envs, 1 asset, window=64", 65536, 1, 64),
+    3: ("256k envs, 30 assets, window=64", 262144, 30, 64),
+    4: ("1M envs, 30 assets, window=128", 1048576, 30, 128),
+    5: ("512k envs per GPU, 30 assets, window=128 (4M over 8 GPUs)", 524288, 30, 128),
+}
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+TRAJ_T = 16             # steps per trajectory all-gather (N > 1 only)
+# the reference's own PyTorch-CPU path, measured in the build container
+REFERENCE_CPU_QUOTED = {"value": 40497, "unit": "env-steps/s", "cores": 8,
+                        "what": "hmomin/FinEnvs TimeSeriesEnv.step, torch 2.10 CPU, 65536 envs x W64, build container"}
+
+
+def algorithmic_bytes(W: int, A: int) -> int:
+    """obs write 8*W*5A + window read 8*W*4A + 84 B per sleeve + 36 B per env."""
+    return 72 * W * A + 84 * A + 36
+
+
+def make_series(A: int):
+    from finenvs_amd.data import synthetic
+
+    return synthetic.synthetic_series(65, A, 390, 1234)
+
+
+def cpu_baseline(A: int, W: int, budget_s: float = 12.0):
+    """The oracle (C restatement of the reference, OpenMP) on this box's host cores,
+    on a bounded sample of the same workload."""
+    from oracle import fe_oracle as fo
+
+    fo.build()
+    prices, day_id, _ = make_series(A)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    cores = os.cpu_count() or 1
+    n = 65536 if A == 1 else 4096
+    env = fo.OracleEnv(P, LR, W, num_envs=n, redraw_mode=1, seed=1, nthreads=cores)
+    g = torch.Generator().manual_seed(7)
+    acts = [(torch.rand((n, A), generator=g) * 2 - 1).float().numpy() for _ in range(8)]
+    env.step(acts[0])
+    t0 = time.perf_counter()
+    k = 0
+    while True:
+        env.step(acts[k % 8])
+        k += 1
+        el = time.perf_counter() - t0
+        if el > budget_s or k >= 400:
+            break
+    return {"value": n * k / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{k} steps of {n} envs x {A} assets x W{W} (oracle/fe_oracle.c, OpenMP {cores} threads, {el:.1f} s)",
+            "reference_quoted": REFERENCE_CPU_QUOTED}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--redraw", default="device", choices=["device", "torch"])
+    ap.add_argument("--obs-f32", action="store_true", help="f32 observations (NOT the reference dtype; extra mode)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    import finenvs_amd
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    name, n_per_gpu, A, W = CONFIGS[args.config]
+    prices, day_id, _ = make_series(A)
+    # config 4's observation is 153.6 GB: a single env-owned buffer (SURVEY section 7 "Capacity")
+    obs_bytes = n_per_gpu * W * 5 * A * (4 if args.obs_f32 else 8)
+    obs_buffers = 2 if 2 * obs_bytes < 200e9 else 1
+    env = finenvs_amd.TimeSeriesEnv(
+        prices=prices, day_id=day_id, num_intervals=W, num_envs=n_per_gpu * world, rank=rank, world_size=world,
+        device_id=local_rank, redraw=args.redraw, seed=1234, obs_buffers=obs_buffers,
+        obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+    N = env.num_envs
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
+    traj = TrajectoryBuffer(TRAJ_T, N, A, device=dev) if world > 1 else None
+    gathered = torch.empty((world, traj._nbytes), dtype=torch.uint8, device=dev) if traj else None
+
+    def one_step(i):
+        a = actions[i % 8]
+        obs, rew, done, _ = env.step(a)
+        if traj is not None:
+            traj.store(a, rew, done)
+            if traj.full():
+                traj.all_gather(out=gathered)
+                traj.clear()
+        return obs
+
+    env.reset()
+    for i in range(args.warmup):
+        one_step(i)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        one_step(i)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # kernel duration: HIP events on the launch stream around every step of a second pass
+    k2 = min(args.steps, 200)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(k2 + 1)]
+    torch.cuda.synchronize()
+    evs[0].record()
+    for i in range(k2):
+        env.step(actions[i % 8])
+        evs[i + 1].record()
+    torch.cuda.synchronize()
+    iv = np.asarray([evs[i].elapsed_time(evs[i + 1]) for i in range(k2)])  # ms
+    kern_ms = float(iv.mean())
+
+    if rank == 0:
+        total_envs = N * world if world == 1 else env.global_num_envs
+        B = algorithmic_bytes(W, A) if not args.obs_f32 else algorithmic_bytes(W, A) - 4 * W * 5 * A
+        achieved = B * N / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                traffic = tj.get(f"config{args.config}", {}).get("bytes_per_launch")
+            except Exception:  # noqa: BLE001
+                traffic = None
+        out = {
+            "metric": "env-steps/sec",
+            "value": total_envs * args.steps / elapsed,
+            "unit": "env-steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32" if args.obs_f32 else "f64",
+            "data": "synthetic",
+            "config": {"workload": name, "envs_per_gpu": N, "num_assets": A, "window": W,
+                       "obs_buffers": obs_buffers, "eval_redraw": args.redraw,
+                       "launch": env.launch_info(),
+                       "trajectory_all_gather_every": TRAJ_T if world > 1 else None},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
+                         "kernel": "fe_env_kernel (fused step)", "kernel_ms": kern_ms,
+                         "kernel_ms_min": float(iv.min()), "algorithmic_bytes_per_env_step": B,
+                         "units_per_launch": N},
+        }
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline(A, W)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,710 @@
+// fe_env.hip -- MI355X (gfx950) implementation of the TimeSeriesEnv hot path.
+//
+// What the reference does with ~660 eager ATen ops and four full-day
+// advanced-index copies per step (finenvs/environments/time_series_env.py,
+// "TSE", lines 277-536) is ONE kernel launch here:
+//
+//   phase 1  one lane per (env, asset) account ("sleeve"): action -> share
+//            delta, six-stage trade, margin checks, reward, done      TSE:298-421,447-496
+//   phase 1b one lane per env: OR of sleeve dones, liquidation fee, reward sum,
+//            evaluate-mode bookkeeping, eval-env redraw                TSE:288-289,498-536
+//   phase 2  the whole workgroup streams the tile's observations: the
+//            (W, 4A) log-return window is copied from the L2/MALL-resident
+//            table into the (W, 5A) observation with the position feature
+//            spliced in, as full 16-byte-per-lane coalesced stores     TSE:423-445
+//
+// A workgroup (256 threads = 4 wavefronts of 64) owns a TILE of EB consecutive
+// envs; tiles are grid-strided.  The observation of a tile is one contiguous
+// region of HBM, so phase 2 is a flat, perfectly coalesced store stream.
+//
+// Arithmetic contract: every (float)/(double) cast is a rounding point of the
+// reference's mixed f32/f64 tensor arithmetic; this file
+// must be compiled with -ffp-contract=off.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <cmath>
+#include <limits>
+#include <new>
+
+#include "finenvs_amd.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return FE_ERR_HIP;
+}
+
+// Exact unsigned 32-bit division by a launch-time constant (Granlund & Montgomery 1994).
+struct FastDiv {
+    uint32_t m, sh1, sh2, d;
+};
+
+FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;  // ceil(log2 d)
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 1 ? l - 1 : 0;
+    return f;
+}
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+    uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+struct Params {
+    const double *P;
+    const double *LR;
+    int64_t *env_idx;
+    int64_t *spot0;
+    float *cash;
+    float *lng;
+    float *sht;
+    double *margin;
+    uint8_t *terminated;
+    float *ep_ret;
+    unsigned long long *counters;
+    const float *actions;
+    void *obs;
+    double *rew;
+    int32_t *done;
+    int64_t N, D, L;
+    int64_t num_tiles;
+    int64_t eval_env;
+    uint64_t seed;
+    int32_t W, A, EB;
+    int32_t evaluate, redraw_mode;
+    uint32_t env_elems;  // W * 5 * A, observation elements per env
+    FastDiv div_chunks;  // by chunks per env
+    FastDiv div_A;
+    float scale32, ms32, c32, imr32, S32;
+    double comm, imr, one_mmr, S;
+};
+
+// ---- Philox4x32-10, the redraw generator of redraw_mode 1 ----
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t counter) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0x46454e56u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// max(x, 0) that lets a NaN through, as torch.relu does
+__device__ __forceinline__ float relu32(float x) { return x > 0.0f ? x : (x != x ? x : 0.0f); }
+__device__ __forceinline__ double relu64(double x) { return x > 0.0 ? x : (x != x ? x : 0.0); }
+
+struct Sleeve {
+    float cash, lng, sht;
+    double margin;
+    double pos_obs;
+    double rew;
+    bool bankrupt;
+};
+
+// One (env, asset) account for one bar: TSE:298-421 (trade), TSE:428-431
+// (position feature), TSE:447-475 (reward).  Pure register arithmetic.
+__device__ __forceinline__ void sleeve_step(const Params &p, float action, double O, double H, double Lo,
+                                            double C, Sleeve &s) {
+    float cash = s.cash, lng = s.lng, sht = s.sht;
+    double margin = s.margin;
+    float comm = 0.0f;  // TSE:305
+
+    // TSE:298-302  round-half-even then clamp
+    float sc = rintf(action * p.scale32);
+    sc = sc < -p.ms32 ? -p.ms32 : sc;
+    sc = sc > p.ms32 ? p.ms32 : sc;
+    float pos = sc < 0.0f ? 0.0f : sc;  // TSE:344-351
+    float neg = sc > 0.0f ? 0.0f : sc;
+
+    // sell long positions first, TSE:353-361
+    float nl = relu32(lng + neg);
+    float sell = lng - nl;
+    neg += sell;
+    comm += sell * p.c32;
+    cash = (float)((double)cash + (double)sell * (O - p.comm));
+    lng = nl;
+
+    // buy back shorts and re-mark the margin account, TSE:367-383
+    float ns = relu32(sht - pos);
+    float bb = sht - ns;
+    pos -= bb;
+    comm += bb * p.c32;
+    cash = (float)((double)cash - (double)bb * (O + p.comm));
+    sht = ns;
+    double nm = (double)(p.imr32 * sht) * O;
+    cash = (float)((double)cash - (nm - margin));
+    margin = nm;
+
+    // long entry unless unaffordable, TSE:385-399
+    if ((double)cash - (double)pos * (O + p.comm) < 0.0) pos = 0.0f;
+    comm += pos * p.c32;
+    cash = (float)((double)cash - (double)pos * (O + p.comm));
+    lng += pos;
+
+    // short entry unless the 150% margin is unaffordable, TSE:401-421
+    float q = -neg;
+    if (((double)cash - p.imr * ((double)q * O)) - (double)(q * p.c32) < 0.0) {
+        neg = 0.0f;
+        q = -neg;
+    }
+    comm += q * p.c32;
+    double req = p.imr * ((double)q * O);
+    cash = (float)((double)cash - (req + (double)(q * p.c32)));
+    margin += req;
+    sht += q;
+
+    // observation feature, rendered post-trade / pre-margin-check, TSE:428-431
+    s.pos_obs = (double)(lng - sht) * C / p.S;
+
+    // reward, TSE:447-475
+    bool done = cash < 0.0f;
+    double rew;
+    {
+        double call = relu64((double)sht * H * p.one_mmr - margin);
+        cash = (float)((double)cash - call);
+        margin += call;
+        done |= cash < 0.0f;
+        rew = -call;
+    }
+    {
+        double rel = relu64(margin - (double)sht * Lo * p.imr);
+        margin -= rel;
+        cash = (float)((double)cash + rel);
+    }
+    {
+        double call = relu64((double)sht * C * p.one_mmr - margin);
+        cash = (float)((double)cash - call);
+        margin += call;
+        done |= cash < 0.0f;
+        rew += -call;
+    }
+    if (done) {
+        lng = 0.0f;
+        sht = 0.0f;
+    }
+    rew += (double)(lng - sht) * (C - O);
+    rew -= (double)comm;
+
+    s.cash = cash; s.lng = lng; s.sht = sht; s.margin = margin;
+    s.rew = rew;
+    s.bankrupt = done;
+}
+
+template <typename OT, int VEC>
+struct alignas(sizeof(OT) * VEC) Pack {
+    OT v[VEC];
+};
+
+// LDS carve-up for a tile of EB envs x A assets (S = EB*A sleeves):
+//   int64 src[EB]  element offset of the window's first row in the LR table
+//   double pos[S]  position feature per sleeve
+//   double rew[S]  sleeve reward before the liquidation fee   (A > 1 only)
+//   float  shr[S]  long+short after the reward step            (A > 1 only)
+//   int    flg[S]  sleeve done flag                            (A > 1 only)
+//   int    any[EB] env-level done                              (A > 1 only)
+__host__ __device__ inline size_t lds_bytes(int EB, int A) {
+    size_t S = (size_t)EB * A;
+    size_t b = (size_t)EB * 8 + S * 8;
+    if (A > 1) b += S * 8 + S * 4 + S * 4 + (size_t)EB * 4;
+    return (b + 15) & ~(size_t)15;
+}
+
+template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY>
+__global__ __launch_bounds__(kBlock) void fe_env_kernel(const Params p) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const int S = EB * A;
+    int64_t *s_src = reinterpret_cast<int64_t *>(smem);
+    double *s_pos = reinterpret_cast<double *>(s_src + EB);
+    double *s_rew = s_pos + S;
+    float *s_shr = reinterpret_cast<float *>(s_rew + S);
+    int *s_flg = reinterpret_cast<int *>(s_shr + S);
+    int *s_any = s_flg + S;
+
+    const int tid = threadIdx.x;
+    const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
+    const int a = SINGLE ? 0 : tid - e * A;
+    const int64_t rs = 4 * (int64_t)A;  // table row stride, doubles
+    const int W = p.W;
+    const int64_t L = p.L;
+    const uint32_t env_elems = p.env_elems;
+    const uint32_t chunks = env_elems / VEC;
+
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        const bool active = e < ebt;
+        const int64_t n = n0 + e;
+        const int64_t sl = n * A + a;  // sleeve index in the (N, A) state arrays
+
+        // ---------------- phase 1: one lane per sleeve ----------------
+        Sleeve s;
+        int64_t idx = 0, s0 = 0;
+        bool sdone = false;
+        if (active) {
+            idx = p.env_idx[n];
+            if constexpr (RESET_ONLY) {
+                s0 = p.spot0[n];
+                int64_t last = s0 + W - 1;
+                last = last < L ? last : L - 1;
+                const double C = p.P[(idx * L + last) * rs + 4 * a + 3];
+                s_pos[e * A + a] = (double)(p.lng[sl] - p.sht[sl]) * C / p.S;
+            } else {
+                s0 = p.spot0[n] + 1;  // TSE:281-282
+                int64_t last = s0 + W - 1;
+                last = last < L ? last : L - 1;  // memory safety only; the done logic keeps last < L
+                const int64_t nxt = last + 1;    // TSE:480
+                const double4 bar = *reinterpret_cast<const double4 *>(p.P + (idx * L + last) * rs + 4 * a);
+                double probe = 0.0;
+                if (nxt < L) probe = p.LR[(idx * L + nxt) * rs + 4 * a];
+                s.cash = p.cash[sl];
+                s.lng = p.lng[sl];
+                s.sht = p.sht[sl];
+                s.margin = p.margin[sl];
+                sleeve_step(p, p.actions[sl], bar.x, bar.y, bar.z, bar.w, s);
+                // termination: bankrupt | end of buffer | next open log-return is NaN, TSE:477-496
+                sdone = s.bankrupt | (nxt >= L) | (probe != probe);
+                s_pos[e * A + a] = s.pos_obs;
+                if constexpr (!SINGLE) {
+                    s_rew[e * A + a] = s.rew;
+                    s_shr[e * A + a] = s.sht + s.lng;  // num_shares, TSE:288
+                    s_flg[e * A + a] = sdone ? 1 : 0;
+                }
+            }
+            if (a == 0) s_src[e] = (idx * L + s0) * rs;
+        }
+
+        // ---------------- phase 1b: one lane per env ----------------
+        if constexpr (!RESET_ONLY) {
+            bool any = sdone;
+            if constexpr (!SINGLE) __syncthreads();
+            if (active && a == 0) {
+                double rew;
+                if constexpr (SINGLE) {
+                    float fee = ((any ? 1.0f : 0.0f) * (s.sht + s.lng)) * p.c32;  // TSE:288-289
+                    rew = s.rew - (double)fee;
+                } else {
+                    any = false;
+                    for (int k = 0; k < A; ++k) any |= s_flg[e * A + k] != 0;
+                    rew = 0.0;
+                    for (int k = 0; k < A; ++k) {  // sleeve contract: sum in asset order
+                        float fee = ((any ? 1.0f : 0.0f) * s_shr[e * A + k]) * p.c32;
+                        double r = s_rew[e * A + k] - (double)fee;
+                        rew = (k == 0) ? r : rew + r;
+                    }
+                    s_any[e] = any ? 1 : 0;
+                }
+                if (any) {
+                    s0 = 0;  // window rewinds to rows 0..W-1, TSE:514-521
+                    if (!p.evaluate && p.redraw_mode == 1 && n == p.eval_env) {  // TSE:504-513
+                        unsigned long long ctr = p.counters[1];
+                        p.env_idx[n] = (int64_t)(((uint64_t)philox_u32(p.seed, ctr) * (uint64_t)p.D) >> 32);
+                        p.counters[1] = ctr + 1;
+                    }
+                }
+                p.spot0[n] = s0;
+                if (p.evaluate) {  // TSE:523-536
+                    const bool term = p.terminated[n] != 0;
+                    if (term) rew = 0.0;
+                    if (any && !term) {
+                        p.terminated[n] = 1;
+                        atomicAdd(&p.counters[0], 1ull);
+                    }
+                    p.ep_ret[n] = (float)((double)p.ep_ret[n] + rew);
+                }
+                p.rew[n] = rew;
+                p.done[n] = any ? 1 : 0;
+            }
+            if constexpr (!SINGLE) {
+                __syncthreads();
+                if (active) any = s_any[e] != 0;
+            }
+            if (active) {  // state write-back with the episodic reset folded in, TSE:498-502
+                p.cash[sl] = any ? p.S32 : s.cash;
+                p.lng[sl] = any ? 0.0f : s.lng;
+                p.sht[sl] = any ? 0.0f : s.sht;
+                p.margin[sl] = any ? 0.0 : s.margin;
+            }
+        }
+        if constexpr (SINGLE || RESET_ONLY) __syncthreads();
+
+        // ---------------- phase 2: flat coalesced observation stream ----------------
+        {
+            const uint32_t total = (uint32_t)ebt * chunks;
+            Pack<OT, VEC> *dst = reinterpret_cast<Pack<OT, VEC> *>(reinterpret_cast<OT *>(p.obs) +
+                                                                    n0 * (int64_t)env_elems);
+#pragma unroll 4
+            for (uint32_t g = tid; g < total; g += kBlock) {
+                const uint32_t ee = fdiv(g, p.div_chunks);
+                const uint32_t c = g - ee * chunks;
+                const double *src = p.LR + s_src[ee];
+                const double *posr = s_pos + ee * A;
+                Pack<OT, VEC> out;
+#pragma unroll
+                for (int i = 0; i < VEC; ++i) {
+                    const uint32_t el = c * VEC + i;
+                    const uint32_t t = el / 5u;       // (row j, asset a) tuple index
+                    const uint32_t k = el - 5u * t;   // 0..3 log-returns, 4 position
+                    const double x = src[4u * t + (k < 4u ? k : 3u)];
+                    const uint32_t aa = SINGLE ? 0u : t - fdiv(t, p.div_A) * (uint32_t)A;
+                    const double pz = posr[aa];
+                    out.v[i] = (OT)(k < 4u ? x : pz);
+                }
+                dst[g] = out;
+            }
+        }
+        __syncthreads();  // LDS is reused by the next tile
+    }
+}
+
+// ---- a18: 100*ln(H/O, L/O, C/O), 100*ln(O_t/C_{t-1}) over the whole series, TSE:179-194 ----
+__global__ __launch_bounds__(kBlock) void fe_logret_kernel(const double *__restrict__ prices,
+                                                           double *__restrict__ out, int64_t T, int32_t A) {
+    const int64_t total = T * A;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t t = i / A;
+        const double4 p = *reinterpret_cast<const double4 *>(prices + 4 * i);
+        const double prev = (t == 0) ? p.x : prices[4 * (i - A) + 3];  // previous close, TSE:188-190
+        double4 o;
+        o.x = 100.0 * log(p.x / prev);
+        o.y = 100.0 * log(p.y / p.x);
+        o.z = 100.0 * log(p.z / p.x);
+        o.w = 100.0 * log(p.w / p.x);
+        *reinterpret_cast<double4 *>(out + 4 * i) = o;
+    }
+}
+
+// ---- a19: per-day slices, NaN-padded, TSE:196-216 ----
+__global__ __launch_bounds__(kBlock) void fe_tables_kernel(const double *__restrict__ series,
+                                                           const int64_t *__restrict__ starts,
+                                                           const int64_t *__restrict__ stops, int64_t D,
+                                                           int64_t L, int32_t A, double *__restrict__ out) {
+    const int64_t rs = 4 * (int64_t)A;
+    const int64_t total = D * L * rs;
+    const double nan = __longlong_as_double(0x7ff8000000000000ll);
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = i / rs, k = i - row * rs;
+        const int64_t d = row / L, r = row - d * L;
+        const int64_t st = starts[d];
+        out[i] = (r <= stops[d] - st) ? series[(st + r) * rs + k] : nan;
+    }
+}
+
+// ---- f1: trajectory slot store ----
+__global__ __launch_bounds__(kBlock) void fe_traj_store_kernel(int64_t N, int64_t NA,
+                                                               const float *__restrict__ actions,
+                                                               const double *__restrict__ rewards,
+                                                               const int32_t *__restrict__ dones,
+                                                               float *__restrict__ ta, double *__restrict__ tr,
+                                                               int32_t *__restrict__ td) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < NA; i += (int64_t)gridDim.x * kBlock) {
+        ta[i] = actions[i];
+        if (i < N) {
+            tr[i] = rewards[i];
+            td[i] = dones[i];
+        }
+    }
+}
+
+// ---- f1: discounted returns + advantages, one reverse scan per env (buffer.py:80-100).
+// dtype discipline of the reference: (1 - dones) * gamma is f32; the first product with the
+// f32 last_values is an f32 product, later ones are f64; returns/advantages are stored f32.
+__global__ __launch_bounds__(kBlock) void fe_traj_returns_kernel(const double *__restrict__ rewards,
+                                                                 const int32_t *__restrict__ dones,
+                                                                 const float *__restrict__ values,
+                                                                 const float *__restrict__ last_values,
+                                                                 int64_t T, int64_t N, float g32,
+                                                                 float *__restrict__ returns,
+                                                                 float *__restrict__ adv) {
+    for (int64_t n = blockIdx.x * (int64_t)kBlock + threadIdx.x; n < N; n += (int64_t)gridDim.x * kBlock) {
+        double R = 0.0;
+        for (int64_t t = T - 1; t >= 0; --t) {
+            const float factor = (float)(1 - dones[t * N + n]) * g32;
+            if (t == T - 1)
+                R = rewards[t * N + n] + (double)(factor * last_values[n]);
+            else
+                R = rewards[t * N + n] + (double)factor * R;
+            const float r32 = (float)R;
+            returns[t * N + n] = r32;
+            if (adv) adv[t * N + n] = r32 - values[t * N + n];
+        }
+    }
+}
+
+int grid_for(int64_t work_items) {
+    int64_t g = (work_items + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > 256 * 8) g = 256 * 8;
+    return (int)g;
+}
+
+}  // namespace
+
+struct fe_env {
+    fe_config cfg;
+    Params p;
+    int grid;
+    int vec;  // observation elements per 16-byte store (1 when the env size is odd)
+    size_t lds;
+    bool bound;
+};
+
+template <bool RESET_ONLY>
+static int launch_env(fe_env *env, hipStream_t st) {
+    const Params &p = env->p;
+    const bool f32 = env->cfg.obs_is_f32 != 0;
+    const bool single = p.A == 1;
+    dim3 g(env->grid), b(kBlock);
+    const size_t lds = env->lds;
+#define FE_LAUNCH(OT, VEC)                                                                       \
+    do {                                                                                         \
+        if (single)                                                                              \
+            hipLaunchKernelGGL((fe_env_kernel<OT, VEC, true, RESET_ONLY>), g, b, lds, st, p);     \
+        else                                                                                     \
+            hipLaunchKernelGGL((fe_env_kernel<OT, VEC, false, RESET_ONLY>), g, b, lds, st, p);    \
+    } while (0)
+    if (f32) {
+        if (env->vec == 4) FE_LAUNCH(float, 4);
+        else if (env->vec == 2) FE_LAUNCH(float, 2);
+        else FE_LAUNCH(float, 1);
+    } else {
+        if (env->vec == 2) FE_LAUNCH(double, 2);
+        else FE_LAUNCH(double, 1);
+    }
+#undef FE_LAUNCH
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");
+    return FE_OK;
+}
+
+extern "C" {
+
+int fe_version(void) { return FE_ABI_VERSION; }
+
+const char *fe_last_error(void) { return g_err; }
+
+int fe_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}
+
+int fe_env_create(const fe_config *cfg, const double *prices, const double *logret, fe_env **out) {
+    if (!cfg || !out) return fail(FE_ERR_ARG, "fe_env_create: null argument");
+    if (!prices || !logret) return fail(FE_ERR_ARG, "fe_env_create: prices and logret tables are required");
+    if (cfg->N < 1 || cfg->D < 1) return fail(FE_ERR_ARG, "fe_env_create: N=%lld D=%lld must be >= 1", (long long)cfg->N, (long long)cfg->D);
+    if (cfg->W < 1 || cfg->L <= cfg->W)
+        return fail(FE_ERR_ARG, "fe_env_create: need 1 <= W < L (W=%lld, L=%lld)", (long long)cfg->W, (long long)cfg->L);
+    if (cfg->A < 1 || cfg->A > FE_MAX_ASSETS)
+        return fail(FE_ERR_ARG, "fe_env_create: A=%lld outside 1..%lld", (long long)cfg->A, (long long)FE_MAX_ASSETS);
+    if (cfg->max_shares < 0) return fail(FE_ERR_ARG, "fe_env_create: max_shares < 0");
+    if (cfg->redraw_mode != 0 && cfg->redraw_mode != 1) return fail(FE_ERR_ARG, "fe_env_create: redraw_mode must be 0 or 1");
+    if (cfg->eval_env >= cfg->N) return fail(FE_ERR_ARG, "fe_env_create: eval_env out of range");
+    const int64_t env_elems = (int64_t)cfg->W * 5 * cfg->A;
+    if (env_elems > (1ll << 24)) return fail(FE_ERR_ARG, "fe_env_create: W*5*A too large");
+    int ndev = 0;
+    hipError_t he = hipGetDeviceCount(&ndev);
+    if (he != hipSuccess || ndev < 1) {
+        (void)hipGetLastError();
+        return fail(FE_ERR_HIP, "fe_env_create: no HIP device (this library has no CPU path)");
+    }
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if ((he = hipGetDevice(&dev)) != hipSuccess) return hip_fail(he, "hipGetDevice");
+    if ((he = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return hip_fail(he, "hipGetDeviceProperties");
+
+    fe_env *env = new (std::nothrow) fe_env();
+    if (!env) return fail(FE_ERR_ARG, "fe_env_create: out of host memory");
+    env->cfg = *cfg;
+    env->bound = false;
+    const int A = cfg->A;
+    // tile: as many envs as fit one sleeve per lane, but keep >= ~8 tiles per CU in flight
+    const int64_t want_tiles = (int64_t)prop.multiProcessorCount * 8;
+    int64_t EB = kBlock / A;
+    if (EB < 1) EB = 1;
+    const char *ov = getenv("FE_TILE_ENVS");
+    if (ov && atoi(ov) > 0) {
+        EB = atoi(ov);
+        if (EB * A > kBlock) EB = kBlock / A > 0 ? kBlock / A : 1;
+    } else {
+        int64_t by_n = cfg->N / want_tiles;
+        if (by_n < 1) by_n = 1;
+        if (EB > by_n) EB = by_n;
+    }
+    const int elem_bytes = cfg->obs_is_f32 ? 4 : 8;
+    int vec = 16 / elem_bytes;
+    while (vec > 1 && env_elems % vec != 0) vec /= 2;
+    env->vec = vec;
+    const int64_t num_tiles = (cfg->N + EB - 1) / EB;
+    int64_t grid = num_tiles < want_tiles ? num_tiles : want_tiles;
+    if (grid > 8) grid -= grid % 8;  // keep the tile -> XCD label stable across grid strides
+    env->grid = (int)grid;
+    env->lds = lds_bytes((int)EB, A);
+
+    Params &p = env->p;
+    memset(&p, 0, sizeof(p));
+    p.P = prices;
+    p.LR = logret;
+    p.N = cfg->N; p.D = cfg->D; p.L = cfg->L;
+    p.W = cfg->W; p.A = A; p.EB = (int)EB;
+    p.num_tiles = num_tiles;
+    p.eval_env = cfg->evaluate ? -1 : cfg->eval_env;
+    p.seed = cfg->seed;
+    p.evaluate = cfg->evaluate ? 1 : 0;
+    p.redraw_mode = cfg->redraw_mode;
+    p.env_elems = (uint32_t)env_elems;
+    p.div_chunks = make_fastdiv((uint32_t)(env_elems / vec));
+    p.div_A = make_fastdiv((uint32_t)A);
+    p.scale32 = (float)((double)cfg->max_shares + 0.5);
+    p.ms32 = (float)cfg->max_shares;
+    p.c32 = (float)cfg->commission;
+    p.imr32 = (float)cfg->init_margin;
+    p.S32 = (float)cfg->starting_balance;
+    p.comm = cfg->commission;
+    p.imr = cfg->init_margin;
+    p.one_mmr = 1.0 + cfg->maint_margin;
+    p.S = cfg->starting_balance;
+    *out = env;
+    return FE_OK;
+}
+
+int fe_env_bind_state(fe_env *env, int64_t *env_idx, int64_t *spot0, float *cash, float *long_shares,
+                      float *short_shares, double *margin, uint8_t *terminated, float *episode_returns,
+                      int64_t *counters) {
+    if (!env) return fail(FE_ERR_ARG, "fe_env_bind_state: null env");
+    if (!env_idx || !spot0 || !cash || !long_shares || !short_shares || !margin || !counters)
+        return fail(FE_ERR_ARG, "fe_env_bind_state: null state pointer");
+    if (env->cfg.evaluate && (!terminated || !episode_returns))
+        return fail(FE_ERR_ARG, "fe_env_bind_state: evaluate mode needs terminated and episode_returns");
+    Params &p = env->p;
+    p.env_idx = env_idx; p.spot0 = spot0; p.cash = cash; p.lng = long_shares; p.sht = short_shares;
+    p.margin = margin; p.terminated = terminated; p.ep_ret = episode_returns;
+    p.counters = reinterpret_cast<unsigned long long *>(counters);
+    env->bound = true;
+    return FE_OK;
+}
+
+int fe_env_reset_obs(fe_env *env, void *obs, void *stream) {
+    if (!env || !obs) return fail(FE_ERR_ARG, "fe_env_reset_obs: null argument");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_reset_obs: state not bound");
+    env->p.obs = obs;
+    return launch_env<true>(env, (hipStream_t)stream);
+}
+
+int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones, void *stream) {
+    if (!env || !actions || !obs || !rewards || !dones) return fail(FE_ERR_ARG, "fe_env_step: null argument");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step: state not bound");
+    env->p.actions = actions;
+    env->p.obs = obs;
+    env->p.rew = rewards;
+    env->p.done = dones;
+    return launch_env<false>(env, (hipStream_t)stream);
+}
+
+int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream) {
+    if (!env || !env->bound) return fail(FE_ERR_STATE, "fe_env_set_day: env not bound");
+    if (env_index < 0 || env_index >= env->cfg.N || day < 0 || day >= env->cfg.D)
+        return fail(FE_ERR_ARG, "fe_env_set_day: env %lld / day %lld out of range", (long long)env_index, (long long)day);
+    hipError_t he = hipMemcpyAsync(env->p.env_idx + env_index, &day, sizeof(int64_t), hipMemcpyHostToDevice,
+                                   (hipStream_t)stream);
+    if (he != hipSuccess) return hip_fail(he, "fe_env_set_day");
+    // the source is a stack variable: make the copy complete before it goes away
+    he = hipStreamSynchronize((hipStream_t)stream);
+    if (he != hipSuccess) return hip_fail(he, "fe_env_set_day sync");
+    return FE_OK;
+}
+
+int fe_env_launch_info(const fe_env *env, int32_t *grid, int32_t *block, int32_t *tile_envs, int32_t *lds) {
+    if (!env) return fail(FE_ERR_ARG, "fe_env_launch_info: null env");
+    if (grid) *grid = env->grid;
+    if (block) *block = kBlock;
+    if (tile_envs) *tile_envs = env->p.EB;
+    if (lds) *lds = (int32_t)env->lds;
+    return FE_OK;
+}
+
+int fe_env_destroy(fe_env *env) {
+    delete env;
+    return FE_OK;
+}
+
+int fe_build_logret(const double *prices, double *out, int64_t T, int32_t A, void *stream) {
+    if (!prices || !out || T < 1 || A < 1) return fail(FE_ERR_ARG, "fe_build_logret: bad argument");
+    hipLaunchKernelGGL(fe_logret_kernel, dim3(grid_for(T * A)), dim3(kBlock), 0, (hipStream_t)stream, prices, out, T, A);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_build_logret launch");
+    return FE_OK;
+}
+
+int fe_build_tables(const double *series, const int64_t *starts, const int64_t *stops, int64_t D, int64_t L,
+                    int32_t A, double *out, void *stream) {
+    if (!series || !starts || !stops || !out || D < 1 || L < 1 || A < 1)
+        return fail(FE_ERR_ARG, "fe_build_tables: bad argument");
+    hipLaunchKernelGGL(fe_tables_kernel, dim3(grid_for(D * L * 4 * A)), dim3(kBlock), 0, (hipStream_t)stream, series,
+                       starts, stops, D, L, A, out);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_build_tables launch");
+    return FE_OK;
+}
+
+int fe_traj_store(int64_t t, int64_t N, int32_t A, const float *actions, const double *rewards,
+                  const int32_t *dones, float *traj_actions, double *traj_rewards, int32_t *traj_dones,
+                  void *stream) {
+    if (t < 0 || N < 1 || A < 1 || !actions || !rewards || !dones || !traj_actions || !traj_rewards || !traj_dones)
+        return fail(FE_ERR_ARG, "fe_traj_store: bad argument");
+    const int64_t NA = N * A;
+    hipLaunchKernelGGL(fe_traj_store_kernel, dim3(grid_for(NA)), dim3(kBlock), 0, (hipStream_t)stream, N, NA, actions,
+                       rewards, dones, traj_actions + t * NA, traj_rewards + t * N, traj_dones + t * N);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_traj_store launch");
+    return FE_OK;
+}
+
+int fe_traj_returns(const double *rewards, const int32_t *dones, const float *values, const float *last_values,
+                    int64_t T, int64_t N, double gamma, float *returns, float *advantages, void *stream) {
+    if (!rewards || !dones || !last_values || !returns || T < 1 || N < 1 || (advantages && !values))
+        return fail(FE_ERR_ARG, "fe_traj_returns: bad argument");
+    hipLaunchKernelGGL(fe_traj_returns_kernel, dim3(grid_for(N)), dim3(kBlock), 0, (hipStream_t)stream, rewards, dones,
+                       values, last_values, T, N, (float)gamma, returns, advantages);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_traj_returns launch");
+    return FE_OK;
+}
+
+}  // extern "C"

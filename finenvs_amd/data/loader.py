@@ -1,0 +1,124 @@
+"""CSV -> market-hours series -> per-day episode bounds (host side, runs once).
+
+Behavioural restatement of the reference's init path (TSE = finenvs/environments/
+time_series_env.py), re-designed:
+
+* file lookup by dataset key with the reference's error behaviour (TSE:47-73),
+* CSV rows ``Date,Time,Open,High,Low,Close,Volume`` (TSE:80-88), Volume dropped (TSE:170),
+* market-hours filter 09:30 <= time <= 15:59 inclusive (TSE:90-91),
+* per date, in order of first appearance: rows ``[first - W, last]``; dates whose
+  backtracked start would be negative are skipped; L = longest episode (TSE:127-152).
+
+Differences by design: bounds are computed in O(T) with numpy instead of the
+reference's O(days x rows) mask scan (TSE:141-148), and there is NO bounds cache
+file -- the reference's JSON cache is keyed by dataset key only and silently goes
+stale when num_intervals changes (TSE:104-106).  The log-return transform and the
+NaN-padded (D, L, 4A) tables are built on the GPU (csrc/fe_env.hip).
+"""
+from __future__ import annotations
+
+import os
+from glob import glob
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+POSSIBLE_KEYS = ["dummy", "train", "valid", "test"]
+OPEN_SECONDS = (9 * 60 + 30) * 60
+LAST_SECONDS = (15 * 60 + 59) * 60
+
+
+def get_data_dir_name(instrument_name: str) -> str:
+    """TSE:47-51: a name containing "data" is a path; otherwise <package>/data/<name>
+    (or $FINENVS_DATA_DIR/<name> when that variable is set)."""
+    if "data" not in instrument_name:
+        root = os.environ.get("FINENVS_DATA_DIR") or os.path.dirname(os.path.realpath(__file__))
+        return os.path.join(root, instrument_name)
+    return instrument_name
+
+
+def determine_file_key(key_attempt: str) -> str:
+    """TSE:53-58."""
+    for possible_key in POSSIBLE_KEYS:
+        if possible_key in key_attempt:
+            return possible_key
+    raise Exception("dataset_key expected to be one of: " + str(POSSIBLE_KEYS))
+
+
+def find_file_by_key(data_dir_name: str, key: str) -> str:
+    """TSE:60-73: exactly one ``*key*.csv`` in the directory, else Exception."""
+    filenames = glob(os.path.join(data_dir_name, "*" + key + "*.csv"))
+    if len(filenames) == 0:
+        raise Exception(f"No file was found in {data_dir_name} with key ({key})")
+    if len(filenames) > 1:
+        raise Exception(f"More than one file was found in {data_dir_name} with key ({key})")
+    return filenames[0]
+
+
+def read_csv_series(path: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """One instrument: (prices (T,4) f64 O,H,L,C; day_id (T,) i64; second-of-day (T,) i64),
+    already restricted to market hours.  day_id numbers dates by first appearance."""
+    import pandas as pd  # host-side parsing only
+
+    df = pd.read_csv(path, names=["Date", "Time", "Open", "High", "Low", "Close", "Volume"], dtype={"Date": str, "Time": str})
+    t = df["Time"].str.split(":", expand=True).astype(np.int64)
+    sec = t[0].values * 3600 + t[1].values * 60 + (t[2].values if t.shape[1] > 2 else 0)
+    keep = (sec >= OPEN_SECONDS) & (sec <= LAST_SECONDS)
+    dates = df["Date"].values[keep]
+    _, first_pos, inv = np.unique(dates, return_index=True, return_inverse=True)
+    order = np.argsort(np.argsort(first_pos))  # rank of each unique date by first appearance
+    day_id = order[inv].astype(np.int64)
+    prices = np.ascontiguousarray(df[["Open", "High", "Low", "Close"]].values[keep], dtype=np.float64)
+    return prices, day_id, sec[keep].astype(np.int64)
+
+
+def read_csv_portfolio(paths: Sequence[str]) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """A instruments on a shared calendar: rows present in every file (inner join on
+    date + time, in the first file's order), columns 4a..4a+3 = asset a."""
+    if len(paths) == 1:
+        return read_csv_series(paths[0])
+    import pandas as pd
+
+    frames = []
+    for a, p in enumerate(paths):
+        df = pd.read_csv(p, names=["Date", "Time", "Open", "High", "Low", "Close", "Volume"], dtype={"Date": str, "Time": str})
+        df = df.drop(columns=["Volume"]).set_index(["Date", "Time"])
+        df.columns = [f"{c}{a}" for c in df.columns]
+        frames.append(df)
+    joined = frames[0].join(frames[1:], how="inner").reset_index()
+    t = joined["Time"].str.split(":", expand=True).astype(np.int64)
+    sec = t[0].values * 3600 + t[1].values * 60 + (t[2].values if t.shape[1] > 2 else 0)
+    keep = (sec >= OPEN_SECONDS) & (sec <= LAST_SECONDS)
+    dates = joined["Date"].values[keep]
+    _, first_pos, inv = np.unique(dates, return_index=True, return_inverse=True)
+    order = np.argsort(np.argsort(first_pos))
+    cols = [c for c in joined.columns if c not in ("Date", "Time")]
+    prices = np.ascontiguousarray(joined[cols].values[keep], dtype=np.float64)
+    return prices, order[inv].astype(np.int64), sec[keep].astype(np.int64)
+
+
+def episode_bounds(day_id: np.ndarray, num_intervals: int) -> Tuple[np.ndarray, np.ndarray, int]:
+    """(starts, stops, max_length) per TSE:127-152, O(T).
+
+    For each date in order of first appearance: first/last row carrying that date;
+    start = first - num_intervals; dates with start < 0 are skipped.
+    """
+    day_id = np.asarray(day_id, dtype=np.int64)
+    T = day_id.shape[0]
+    if T == 0:
+        return np.zeros(0, np.int64), np.zeros(0, np.int64), 0
+    uniq, first = np.unique(day_id, return_index=True)
+    last = T - 1 - np.unique(day_id[::-1], return_index=True)[1]
+    order = np.argsort(first, kind="stable")
+    first, last = first[order], last[order]
+    start = first - int(num_intervals)
+    ok = start >= 0
+    starts = start[ok].astype(np.int64)
+    stops = last[ok].astype(np.int64)
+    max_length = int((stops - starts + 1).max()) if starts.size else 0
+    return starts, stops, max_length
+
+
+def padding_rows(starts: np.ndarray, stops: np.ndarray, max_length: int) -> List[int]:
+    """Rows of NaN padding per day (what the reference draws torch.rand for, TSE:205-210)."""
+    return [int(max_length - (b - a + 1)) for a, b in zip(starts, stops)]

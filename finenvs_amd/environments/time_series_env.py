@@ -1,0 +1,329 @@
+"""TimeSeriesEnv: the reference's Gym-like vectorised trading env, MI355X-native.
+
+Drop-in for ``finenvs.environments.time_series_env.TimeSeriesEnv`` ("TSE"): same
+constructor arguments (TSE:15-29), same ``reset()`` / ``step(actions)`` /
+``get_env_args()`` protocol (TSE:236-243, 277-296, 423-435), same attributes
+callers read (``num_envs, num_obs, num_acts, device, action_space,
+observation_space, cash, margin, long_shares, short_shares, env_indices,
+env_pointers, env_spots``).  The per-step state transition is one fused HIP
+kernel behind the C ABI of include/finenvs_amd.h; this class only allocates
+torch tensors, hands their device pointers to that ABI and launches on torch's
+current stream.  There is no CPU path.
+
+Keyword-only extensions: ``num_envs`` (env n -> day n mod D), ``num_assets`` /
+``prices`` / ``day_id`` (tensor input, multi-asset "sleeve" contract of
+DESIGN.md), ``tables`` (ready-made (D,L,4A) price/log-return tables),
+``obs_dtype``, ``obs_buffers``, ``redraw``, ``seed``, ``env_indices``, ``rank`` /
+``world_size`` (contiguous env shards, one process per GPU).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional, Sequence, Tuple, Union
+
+import numpy as np
+import torch
+
+from .. import _lib
+from ..base_object import BaseObject
+from ..data import loader
+from ..device_utils import set_device
+from ..rng import redraw_day
+from ..spaces import Box
+
+
+def shard_range(num_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
+    """Contiguous block of envs owned by ``rank``."""
+    base, rem = divmod(num_envs, world_size)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+class TimeSeriesEnv(BaseObject):
+    def __init__(
+        self,
+        instrument_name: Union[str, Sequence[str]] = "synthetic",
+        dataset_key: str = "dummy",
+        num_intervals: int = 390,
+        max_shares: int = 5,
+        starting_balance: float = 10000,
+        per_share_commission: float = 0.01,
+        initial_margin_requirement: float = 1.5,
+        maintenance_margin_requirement: float = 0.25,
+        evaluate: bool = False,
+        device_id: int = 0,
+        *,
+        num_envs: Optional[int] = None,
+        num_assets: Optional[int] = None,
+        prices=None,
+        day_id=None,
+        tables=None,
+        obs_dtype: torch.dtype = torch.float64,
+        obs_buffers: int = 2,
+        redraw: str = "torch",
+        seed: int = 0,
+        env_indices=None,
+        rank: int = 0,
+        world_size: int = 1,
+    ):
+        self.instrument_name = instrument_name if isinstance(instrument_name, str) else "+".join(instrument_name)
+        self.num_intervals = int(num_intervals)
+        self.max_shares = max_shares
+        self.starting_balance = starting_balance
+        self.per_share_commission = per_share_commission
+        self.initial_margin_requirement = initial_margin_requirement
+        self.maintenance_margin_requirement = maintenance_margin_requirement
+        self.log_return_scale_factor = 100
+        self.evaluate = bool(evaluate)
+        if redraw not in ("torch", "device"):
+            raise ValueError("redraw must be 'torch' (reference RNG stream) or 'device' (Philox, no host sync)")
+        if obs_dtype not in (torch.float64, torch.float32):
+            raise ValueError("obs_dtype must be torch.float64 or torch.float32")
+        self.redraw = redraw
+        self.seed = int(seed)
+        self.obs_dtype = obs_dtype
+        self.rank, self.world_size = int(rank), int(world_size)
+        # dataset-key / file errors come first, exactly as in the reference (TSE:38-40)
+        from_files = prices is None and tables is None
+        if from_files:
+            names = [instrument_name] if isinstance(instrument_name, str) else list(instrument_name)
+            self.file_key = loader.determine_file_key(dataset_key)
+            self.data_dir_name = loader.get_data_dir_name(names[0])
+            self.filename = [loader.find_file_by_key(loader.get_data_dir_name(n), self.file_key) for n in names]
+        self.device = set_device(device_id)
+        self._lib = _lib.load()
+        self._dev = torch.device(self.device)
+        with torch.cuda.device(self._dev):
+            self._build_tables(from_files, prices, day_id, tables, num_assets)
+            self.set_spaces()
+            self.set_environment_params(num_envs, env_indices, obs_buffers)
+
+    # ------------------------------------------------------------------ init path
+    def _stream(self) -> int:
+        return torch.cuda.current_stream(self._dev).cuda_stream
+
+    def _build_tables(self, from_files, prices, day_id, tables, num_assets) -> None:
+        """process_data / set_up_environments (TSE:75-101, 165-216) with the transform and the
+        NaN-padded slicing done on the GPU."""
+        W = self.num_intervals
+        if tables is not None:
+            P, LR = tables
+            self.price_environments = torch.as_tensor(P, dtype=torch.float64).to(self._dev).contiguous()
+            self.log_return_environments = torch.as_tensor(LR, dtype=torch.float64).to(self._dev).contiguous()
+            if self.price_environments.shape != self.log_return_environments.shape or self.price_environments.dim() != 3:
+                raise ValueError("tables must be two (D, L, 4*A) arrays of equal shape")
+            pad = torch.isnan(self.price_environments[:, :, 0]).sum(dim=1).tolist()
+            self._padding_rows = [int(x) for x in pad]
+        else:
+            if from_files:
+                series, day_id, _ = loader.read_csv_portfolio(self.filename)
+            else:
+                series = prices.detach().cpu().numpy() if isinstance(prices, torch.Tensor) else np.asarray(prices)
+                series = np.ascontiguousarray(series, dtype=np.float64)
+                if day_id is None:
+                    raise ValueError("prices= needs day_id= (one date label per row, market hours only)")
+                day_id = day_id.detach().cpu().numpy() if isinstance(day_id, torch.Tensor) else np.asarray(day_id)
+            if series.ndim != 2 or series.shape[1] % 4 != 0:
+                raise ValueError("price series must be (T, 4*A): O,H,L,C per asset")
+            starts, stops, L = loader.episode_bounds(day_id, W)
+            if len(starts) == 0:
+                raise Exception("no trading day has num_intervals bars of history before it")
+            self._padding_rows = loader.padding_rows(starts, stops, L)
+            T, c4 = series.shape
+            A = c4 // 4
+            st = self._stream()
+            self.dataset = torch.from_numpy(series).to(self._dev)
+            self.log_return_dataset = torch.empty_like(self.dataset)
+            _lib.check(self._lib.fe_build_logret(self.dataset.data_ptr(), self.log_return_dataset.data_ptr(), T, A, st))
+            d_starts = torch.from_numpy(starts).to(self._dev)
+            d_stops = torch.from_numpy(stops).to(self._dev)
+            D = len(starts)
+            self.price_environments = torch.empty((D, L, c4), dtype=torch.float64, device=self._dev)
+            self.log_return_environments = torch.empty((D, L, c4), dtype=torch.float64, device=self._dev)
+            for src, dst in ((self.dataset, self.price_environments), (self.log_return_dataset, self.log_return_environments)):
+                _lib.check(self._lib.fe_build_tables(src.data_ptr(), d_starts.data_ptr(), d_stops.data_ptr(), D, L, A,
+                                                     dst.data_ptr(), st))
+            torch.cuda.current_stream(self._dev).synchronize()  # d_starts/d_stops go out of scope
+        D, L, c4 = self.price_environments.shape
+        self.num_assets = c4 // 4
+        if num_assets is not None and int(num_assets) != self.num_assets:
+            raise ValueError(f"num_assets={num_assets} but the price data has {self.num_assets} assets")
+        if not (1 <= self.num_assets <= _lib.FE_MAX_ASSETS):
+            raise ValueError(f"num_assets must be in 1..{_lib.FE_MAX_ASSETS}")
+        if L <= W:
+            raise ValueError("every episode needs at least one bar after the window")
+        self.values_per_interval = 4
+        if self.redraw == "torch":
+            # the reference burns global-generator draws while filling its NaN padding
+            # (TSE:207-210); replay them so a seeded run sees the same stream afterwards
+            for rem in self._padding_rows:
+                if rem > 0:
+                    torch.rand((rem, 4), device=self._dev)
+
+    def set_spaces(self) -> None:
+        """TSE:218-234, widened to A assets: per asset 4 log-returns + position."""
+        A = self.num_assets
+        self.num_obs = (self.values_per_interval + 1) * A
+        self.num_acts = A
+        self.action_space = Box(np.ones(self.num_acts) * -1.0, np.ones(self.num_acts) * +1.0, dtype=np.float64)
+        self.observation_space = Box(
+            np.ones((self.num_intervals, self.num_obs)) * -np.inf,
+            np.ones((self.num_intervals, self.num_obs)) * +np.inf,
+            dtype=np.float64,
+        )
+
+    def get_env_args(self) -> Dict:
+        """TSE:236-243."""
+        return {
+            "env_name": self.instrument_name,
+            "num_envs": self.num_envs,
+            "num_observations": self.num_obs,
+            "num_actions": self.num_acts,
+            "sequence_length": self.num_intervals,
+        }
+
+    def set_environment_params(self, num_envs, env_indices, obs_buffers) -> None:
+        """TSE:245-269: state tensors; plus the C-ABI env object."""
+        dev = self._dev
+        D, L, _ = self.price_environments.shape
+        A, W = self.num_assets, self.num_intervals
+        training = not self.evaluate
+        if env_indices is not None:
+            idx = torch.as_tensor(env_indices, dtype=torch.int64).to(dev).contiguous().clone()
+            total = idx.shape[0]
+            lo, hi = 0, total
+            self._eval_env = total - 1 if training else -1
+        else:
+            total = int(num_envs) if num_envs is not None else D + (1 if training else 0)
+            if total < 1:
+                raise ValueError("num_envs must be >= 1")
+            lo, hi = shard_range(total, self.rank, self.world_size)
+            idx = (torch.arange(lo, hi, dtype=torch.int64, device=dev) % D).contiguous()
+            # the last env overall is the evaluation env and starts on a random day (TSE:253-257)
+            has_eval = training and hi == total and hi > lo
+            self._eval_env = (hi - lo - 1) if has_eval else -1
+            if training and self.redraw == "torch":
+                first = torch.randint(0, D, (1,), device=dev)  # drawn on every rank to keep streams aligned
+                if has_eval:
+                    idx[-1:] = first
+            elif has_eval:
+                idx[-1] = redraw_day(self.seed, 0, D)
+        if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= D):
+            raise ValueError("env_indices out of range")
+        self.env_indices = idx
+        self.num_envs = int(idx.shape[0])
+        self.global_num_envs = total
+        self.env_offset = lo
+        N = self.num_envs
+        if N < 1:
+            raise ValueError("this rank owns no envs")
+        self._spot0 = torch.zeros((N,), dtype=torch.int64, device=dev)
+        self.cash = self.starting_balance * torch.ones((N, A), device=dev)
+        self.long_shares = torch.zeros((N, A), device=dev)
+        self.short_shares = torch.zeros((N, A), device=dev)
+        self.margin = torch.zeros((N, A), dtype=torch.float64, device=dev)
+        self.terminated_episodes = torch.zeros((N,), dtype=torch.uint8, device=dev)
+        self.episode_returns = torch.zeros((N,), device=dev)
+        # counters[0] = envs terminated so far (evaluate mode), counters[1] = redraw counter
+        self._counters = torch.zeros((2,), dtype=torch.int64, device=dev)
+        if training and self.redraw == "device":
+            self._counters[1] = 1  # draw 0 chose the eval env's first day
+        cfg = _lib.FeConfig(
+            N, D, L, W, A, int(self.max_shares), int(self.evaluate), float(self.starting_balance),
+            float(self.per_share_commission), float(self.initial_margin_requirement),
+            float(self.maintenance_margin_requirement), int(self.obs_dtype == torch.float32),
+            1 if self.redraw == "device" else 0, self.seed, self._eval_env,
+        )
+        handle = C.c_void_p()
+        _lib.check(self._lib.fe_env_create(C.byref(cfg), self.price_environments.data_ptr(),
+                                           self.log_return_environments.data_ptr(), C.byref(handle)))
+        self._handle = handle
+        _lib.check(self._lib.fe_env_bind_state(
+            handle, self.env_indices.data_ptr(), self._spot0.data_ptr(), self.cash.data_ptr(),
+            self.long_shares.data_ptr(), self.short_shares.data_ptr(), self.margin.data_ptr(),
+            self.terminated_episodes.data_ptr(), self.episode_returns.data_ptr(), self._counters.data_ptr()))
+        # observation ring: 0 = fresh tensor per call (reference semantics), k = k env-owned buffers
+        self.obs_buffers = int(obs_buffers)
+        self._obs_ring = [torch.empty((N, W, 5 * A), dtype=self.obs_dtype, device=dev) for _ in range(self.obs_buffers)]
+        self._obs_next = 0
+        self._step_fn = self._lib.fe_env_step
+        self._handle_v = handle.value
+
+    def launch_info(self) -> Dict[str, int]:
+        g, b, t, l = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _lib.check(self._lib.fe_env_launch_info(self._handle, C.byref(g), C.byref(b), C.byref(t), C.byref(l)))
+        return {"grid": g.value, "block": b.value, "tile_envs": t.value, "lds_bytes": l.value}
+
+    def __del__(self):
+        h = getattr(self, "_handle", None)
+        if h is not None and getattr(self, "_lib", None) is not None:
+            self._lib.fe_env_destroy(h)
+            self._handle = None
+
+    # ------------------------------------------------------------------ reference-compatible views
+    @property
+    def env_spots(self) -> torch.Tensor:
+        """(N, W) window row indices; the reference stores this dense array (TSE:261-263)."""
+        return self._spot0.unsqueeze(1) + torch.arange(self.num_intervals, device=self._dev)
+
+    @property
+    def env_pointers(self) -> torch.Tensor:
+        """Steps since the last reset; always equal to env_spots[:, 0] (TSE:281-282, 514)."""
+        return self._spot0.clone()
+
+    def reset_evaluation_metrics(self) -> None:
+        """TSE:271-275."""
+        self.terminated_episodes.zero_()
+        self.episode_returns.zero_()
+        self._counters[0] = 0
+
+    # ------------------------------------------------------------------ hot path
+    def _next_obs(self) -> torch.Tensor:
+        if self.obs_buffers == 0:
+            return torch.empty((self.num_envs, self.num_intervals, 5 * self.num_assets), dtype=self.obs_dtype,
+                               device=self._dev)
+        buf = self._obs_ring[self._obs_next]
+        self._obs_next = (self._obs_next + 1) % self.obs_buffers
+        return buf
+
+    def reset(self) -> torch.Tensor:
+        """Render the observation of the current state (TSE:423-435; it resets nothing)."""
+        obs = self._next_obs()
+        _lib.check(self._lib.fe_env_reset_obs(self._handle, obs.data_ptr(), self._stream()))
+        return obs
+
+    def step(self, actions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, dict]:
+        """One fused launch of TSE:277-296.  Returns (obs (N,W,5A), rewards (N,) f64,
+        dones (N,) int32, info)."""
+        N, A = self.num_envs, self.num_assets
+        if actions.dtype is not torch.float32:
+            actions = actions.float()  # the reference's in-repo callers all pass f32 (SURVEY App. A iii)
+        if actions.numel() != N * A or actions.device != self._dev:
+            raise ValueError(f"actions must hold {N}x{A} values on {self.device}, got {tuple(actions.shape)} on {actions.device}")
+        if not actions.is_contiguous():
+            actions = actions.contiguous()
+        obs = self._next_obs()
+        rewards = torch.empty((N,), dtype=torch.float64, device=self._dev)
+        dones = torch.empty((N,), dtype=torch.int32, device=self._dev)
+        rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
+                           torch.cuda.current_stream(self._dev).cuda_stream)
+        if rc != 0:
+            _lib.check(rc)
+        info: Dict = {}
+        if self.evaluate:
+            info = self.record_evaluation_metrics()
+        elif self.redraw == "torch" and self._eval_env >= 0:
+            # TSE:504-513: the eval env redraws a day from torch's global generator when it finishes
+            if dones[self._eval_env].item():
+                D = self.price_environments.shape[0]
+                self.env_indices[self._eval_env : self._eval_env + 1] = torch.randint(0, D, (1,), device=self._dev)
+        return (obs, rewards, dones, info)
+
+    def record_evaluation_metrics(self) -> Dict:
+        """TSE:523-536.  The per-env part ran inside the step kernel; this is the
+        torch.all(terminated) test and the hand-over of the returns."""
+        if int(self._counters[0].item()) == self.num_envs:
+            info = {"returns": self.episode_returns.clone()}
+            self.reset_evaluation_metrics()
+            return info
+        return {}

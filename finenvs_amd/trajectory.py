@@ -1,0 +1,102 @@
+"""Device-resident trajectory buffer + RCCL all-gather.
+
+Replaces the compact-field half of the reference's PPO buffer
+(finenvs/agents/PPO/buffer.py): ``store`` is one slot write into preallocated
+time-major tensors instead of a ``torch.cat`` per step (buffer.py:33-56, O(T^2)
+bytes moved), and ``returns_and_advantages`` is one reverse-scan kernel per env
+instead of a Python loop over T (buffer.py:80-100), with the reference's dtype
+discipline (f32 discount factor, f64 carry, f32 results).
+
+Multi-GPU: envs are sharded contiguously, one process per GPU; the only
+exchange is ``all_gather`` of these compact fields -- actions (T, n, A) f32,
+rewards (T, n) f64, dones (T, n) i32 -- once per T-step chunk, as ONE collective
+over a single packed byte buffer (RCCL over xGMI when the process group is
+"nccl").  Observations are never gathered: they stay sharded with their learner.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+
+
+class TrajectoryBuffer:
+    def __init__(self, num_steps: int, num_envs: int, num_assets: int = 1, device: str = "cuda:0"):
+        self.T, self.N, self.A = int(num_steps), int(num_envs), int(num_assets)
+        self.device = torch.device(device)
+        T, N, A = self.T, self.N, self.A
+        # one allocation, three typed views: [rewards f64 | actions f32 | dones i32]
+        self._nbytes = T * N * 8 + T * N * A * 4 + T * N * 4
+        self._packed = torch.zeros((self._nbytes,), dtype=torch.uint8, device=self.device)
+        o1 = T * N * 8
+        o2 = o1 + T * N * A * 4
+        self.rewards = self._packed[:o1].view(torch.float64).view(T, N)
+        self.actions = self._packed[o1:o2].view(torch.float32).view(T, N, A)
+        self.dones = self._packed[o2:].view(torch.int32).view(T, N)
+        self.t = 0
+        self._native = self.device.type == "cuda"
+        self._lib = _lib.load() if self._native else None
+
+    def __len__(self) -> int:
+        return self.t
+
+    def full(self) -> bool:
+        return self.t >= self.T
+
+    def clear(self) -> None:
+        self.t = 0
+
+    def store(self, actions: torch.Tensor, rewards: torch.Tensor, dones: torch.Tensor) -> None:
+        if self.t >= self.T:
+            raise IndexError("trajectory buffer is full; call clear()")
+        if self._native:
+            if actions.dtype is not torch.float32:
+                actions = actions.float()
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            _lib.check(self._lib.fe_traj_store(
+                self.t, self.N, self.A, actions.contiguous().data_ptr(), rewards.data_ptr(), dones.data_ptr(),
+                self.actions.data_ptr(), self.rewards.data_ptr(), self.dones.data_ptr(), st))
+        else:  # host tensors: only the gloo rehearsal of the collective uses this
+            self.actions[self.t].copy_(actions.reshape(self.N, self.A))
+            self.rewards[self.t].copy_(rewards)
+            self.dones[self.t].copy_(dones)
+        self.t += 1
+
+    def returns_and_advantages(self, values: torch.Tensor, last_values: torch.Tensor, gamma: float = 0.99
+                               ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(returns, advantages), both (T, N) f32, per buffer.py:80-100.  values (T, N) f32,
+        last_values (N,) f32."""
+        if not self._native:
+            raise RuntimeError("returns_and_advantages runs on the GPU only (no CPU path)")
+        T, N = self.t, self.N
+        values = values.reshape(T, N).float().contiguous()
+        last_values = last_values.reshape(N).float().contiguous()
+        ret = torch.empty((T, N), dtype=torch.float32, device=self.device)
+        adv = torch.empty((T, N), dtype=torch.float32, device=self.device)
+        st = torch.cuda.current_stream(self.device).cuda_stream
+        _lib.check(self._lib.fe_traj_returns(self.rewards.data_ptr(), self.dones.data_ptr(), values.data_ptr(),
+                                             last_values.data_ptr(), T, N, float(gamma), ret.data_ptr(),
+                                             adv.data_ptr(), st))
+        return ret, adv
+
+    # ------------------------------------------------------------------ multi-GPU exchange
+    def all_gather(self, group=None, out: Optional[torch.Tensor] = None):
+        """One collective: every rank receives every rank's packed chunk.
+
+        Returns ``(actions (G, T, n, A), rewards (G, T, n), dones (G, T, n), packed)``
+        as views of the gathered byte buffer (all ranks must own the same n)."""
+        import torch.distributed as dist
+
+        G = dist.get_world_size(group)
+        if out is None:
+            out = torch.empty((G, self._nbytes), dtype=torch.uint8, device=self.device)
+        dist.all_gather_into_tensor(out.view(-1), self._packed, group=group)
+        T, N, A = self.T, self.N, self.A
+        o1 = T * N * 8
+        o2 = o1 + T * N * A * 4
+        rewards = out[:, :o1].contiguous().view(torch.float64).view(G, T, N) if G > 1 else out[0, :o1].view(torch.float64).view(1, T, N)
+        actions = out[:, o1:o2].contiguous().view(torch.float32).view(G, T, N, A) if G > 1 else out[0, o1:o2].view(torch.float32).view(1, T, N, A)
+        dones = out[:, o2:].contiguous().view(torch.int32).view(G, T, N) if G > 1 else out[0, o2:].view(torch.int32).view(1, T, N)
+        return actions, rewards, dones, out

@@ -1,0 +1,153 @@
+/*
+ * finenvs_amd.h -- C ABI of the MI355X-native TimeSeriesEnv hot path.
+ *
+ * The reference (hmomin/FinEnvs) has no FFI: its boundary is the duck-typed
+ * Python protocol of finenvs/environments/time_series_env.py ("TSE").  This
+ * header is the C-ABI a binding for that protocol calls; every entry point
+ * names the reference method it replaces.  finenvs_amd/environments/
+ * time_series_env.py is the ctypes binding.
+ *
+ * Conventions
+ *  - plain C types only; every tensor argument is a DEVICE pointer (HIP
+ *    memory, e.g. torch.Tensor.data_ptr()) unless the comment says host;
+ *  - `stream` is a hipStream_t passed as void* (NULL = default stream); all
+ *    work is enqueued on it and nothing here synchronises with the host;
+ *  - return value 0 on success, negative on error; fe_last_error() returns a
+ *    thread-local description of the last failure;
+ *  - the library creates no threads and owns no tensors: tables, state and
+ *    outputs are caller-owned and must outlive the calls that use them.
+ *
+ * There is deliberately NO CPU implementation behind this ABI: without a GPU
+ * every compute entry point fails with FE_ERR_HIP.
+ */
+#ifndef FINENVS_AMD_H
+#define FINENVS_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FE_ABI_VERSION 1
+#define FE_MAX_ASSETS 256
+
+#define FE_OK 0
+#define FE_ERR_ARG -1  /* invalid argument / configuration */
+#define FE_ERR_HIP -2  /* HIP runtime error (no device, launch failure, ...) */
+#define FE_ERR_STATE -3 /* call made before fe_env_bind_state */
+
+/* Constructor arguments of TimeSeriesEnv (TSE:15-29) plus the build's extensions. */
+typedef struct fe_config {
+    int64_t N;               /* num_envs (reference: days [+1], TSE:246-257)        */
+    int64_t D;               /* days = price_environments.shape[0]                  */
+    int64_t L;               /* padded day length = shape[1] (max_length, TSE:136)  */
+    int32_t W;               /* num_intervals, TSE:19                               */
+    int32_t A;               /* assets per env; 1 in the reference                  */
+    int32_t max_shares;      /* TSE:20                                              */
+    int32_t evaluate;        /* TSE:27                                              */
+    double starting_balance; /* TSE:21                                              */
+    double commission;       /* per_share_commission, TSE:22                        */
+    double init_margin;      /* initial_margin_requirement, TSE:25                  */
+    double maint_margin;     /* maintenance_margin_requirement, TSE:26              */
+    int32_t obs_is_f32;      /* 0: f64 observations (reference), 1: f32             */
+    int32_t redraw_mode;     /* eval-env day redraw (TSE:510-513): 0 = caller draws
+                                and calls fe_env_set_day, 1 = device Philox4x32-10  */
+    uint64_t seed;           /* Philox key for redraw_mode 1                        */
+    int64_t eval_env;        /* local index of the training-mode eval env or -1     */
+} fe_config;
+
+typedef struct fe_env fe_env; /* opaque */
+
+/* FE_ABI_VERSION of the loaded library. */
+int fe_version(void);
+
+/* Thread-local text of the last error returned on this thread ("" if none). */
+const char *fe_last_error(void);
+
+/* Number of HIP devices visible (0 without a GPU); never fails. */
+int fe_device_count(void);
+
+/*
+ * Replaces TimeSeriesEnv.__init__'s device-side setup (TSE:245-269 minus tensor
+ * allocation).  `prices` and `logret` are the (D, L, 4*A) f64 NaN-padded tables
+ * price_environments / log_return_environments (TSE:215-216), asset a in
+ * columns 4a..4a+3 = O,H,L,C.  `cfg` is a host pointer.
+ */
+int fe_env_create(const fe_config *cfg, const double *prices, const double *logret, fe_env **out);
+
+/*
+ * Binds the caller-owned state tensors (TSE:246-275):
+ *   env_idx (N) i64 = env_indices; spot0 (N) i64 = env_spots[:,0] (env_spots[n][j]
+ *   == spot0[n]+j and env_pointers == spot0, so neither is stored);
+ *   cash, long_shares, short_shares (N*A) f32; margin (N*A) f64;
+ *   terminated (N) u8 and episode_returns (N) f32 = evaluate-mode metrics
+ *   (TSE:271-275; may be NULL when cfg.evaluate == 0);
+ *   counters (2) i64: [0] number of terminated envs, [1] redraw counter.
+ */
+int fe_env_bind_state(fe_env *env, int64_t *env_idx, int64_t *spot0, float *cash, float *long_shares,
+                      float *short_shares, double *margin, uint8_t *terminated, float *episode_returns,
+                      int64_t *counters);
+
+/*
+ * Replaces TimeSeriesEnv.reset() (TSE:423-445): renders the observation of the
+ * CURRENT state into obs (N, W, 5*A), f64 or f32 per cfg.obs_is_f32.  Changes no state.
+ */
+int fe_env_reset_obs(fe_env *env, void *obs, void *stream);
+
+/*
+ * Replaces TimeSeriesEnv.step() (TSE:277-296 and everything it calls, TSE:298-536):
+ * one fused launch.  actions (N*A) f32 in [-1,1]; obs (N, W, 5*A); rewards (N) f64;
+ * dones (N) i32.  In evaluate mode the rewards of already-terminated envs are
+ * zeroed and episode_returns accumulated exactly as record_evaluation_metrics
+ * does (TSE:523-536); the caller reads counters[0] to learn when to emit them.
+ */
+int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                void *stream);
+
+/* env_indices[env] = day (the host half of TSE:510-513 when redraw_mode == 0). */
+int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream);
+
+/* Launch geometry chosen for this env (diagnostics / bench reporting). Host pointers. */
+int fe_env_launch_info(const fe_env *env, int32_t *grid, int32_t *block, int32_t *tile_envs,
+                       int32_t *lds_bytes);
+
+int fe_env_destroy(fe_env *env);
+
+/*
+ * Replaces generate_log_return_dataset (TSE:179-194): whole-series transform,
+ * prices/out (T, 4*A) f64.
+ */
+int fe_build_logret(const double *prices, double *out, int64_t T, int32_t A, void *stream);
+
+/*
+ * Replaces generate_environments (TSE:196-216): out[d][r] = series[starts[d]+r]
+ * for r <= stops[d]-starts[d], NaN beyond; series (T, 4*A), out (D, L, 4*A),
+ * starts/stops (D) i64 device pointers.
+ */
+int fe_build_tables(const double *series, const int64_t *starts, const int64_t *stops, int64_t D,
+                    int64_t L, int32_t A, double *out, void *stream);
+
+/*
+ * Trajectory ring (replaces the per-step torch.cat of
+ * finenvs/agents/PPO/buffer.py:33-56): copies one step's compact fields into
+ * slot t of time-major buffers actions (T, N*A) f32, rewards (T, N) f64,
+ * dones (T, N) i32.
+ */
+int fe_traj_store(int64_t t, int64_t N, int32_t A, const float *actions, const double *rewards,
+                  const int32_t *dones, float *traj_actions, double *traj_rewards, int32_t *traj_dones,
+                  void *stream);
+
+/*
+ * Replaces Buffer.compute_returns_and_advantages (buffer.py:80-100) on time-major
+ * (T, N) buffers: rewards f64, dones i32, values f32 (T, N), last_values f32 (N);
+ * writes returns and advantages f32 (T, N).  One reverse scan per env.
+ */
+int fe_traj_returns(const double *rewards, const int32_t *dones, const float *values,
+                    const float *last_values, int64_t T, int64_t N, double gamma, float *returns,
+                    float *advantages, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FINENVS_AMD_H */

@@ -1,0 +1,94 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol
+include/finenvs_amd.h declares, and refuses to compute without a GPU (no fallback)."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(REPO, "include", "finenvs_amd.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from finenvs_amd import _lib
+
+    return _lib.load()
+
+
+def declared_symbols():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(fe_[a-z_]+)\s*\(", text)))
+
+
+def test_header_symbols_are_all_exported_and_bound(lib):
+    from finenvs_amd import _lib
+
+    names = declared_symbols()
+    assert len(names) >= 14
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in the header but not exported"
+        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_version_and_struct_layout(lib, tmp_path):
+    from finenvs_amd import _lib
+
+    assert lib.fe_version() == _lib.FE_ABI_VERSION
+    # the ctypes mirror of fe_config must match the C compiler's layout
+    src = tmp_path / "sz.c"
+    src.write_text(
+        '#include <stdio.h>\n#include <stddef.h>\n#include "finenvs_amd.h"\n'
+        'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(fe_config), offsetof(fe_config, W),'
+        " offsetof(fe_config, starting_balance), offsetof(fe_config, seed), offsetof(fe_config, eval_env));return 0;}\n"
+    )
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(REPO, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    F = _lib.FeConfig
+    assert got == [C.sizeof(F), F.W.offset, F.starting_balance.offset, F.seed.offset, F.eval_env.offset]
+
+
+def test_argument_errors_do_not_need_a_gpu(lib):
+    from finenvs_amd import _lib
+
+    out = C.c_void_p()
+    cfg = _lib.FeConfig(4, 2, 10, 20, 1, 5, 0, 1e4, 0.01, 1.5, 0.25, 0, 0, 0, -1)  # W >= L
+    assert lib.fe_env_create(C.byref(cfg), 8, 8, C.byref(out)) == -1
+    assert b"W" in lib.fe_last_error()
+    cfg = _lib.FeConfig(4, 2, 10, 4, 300, 5, 0, 1e4, 0.01, 1.5, 0.25, 0, 0, 0, -1)  # too many assets
+    assert lib.fe_env_create(C.byref(cfg), 8, 8, C.byref(out)) == -1
+    assert lib.fe_env_create(None, 8, 8, C.byref(out)) == -1
+    assert lib.fe_env_step(None, 8, 8, 8, 8, None) == -1
+    assert lib.fe_build_logret(None, None, 0, 0, None) == -1
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_no_gpu_means_loud_failure_not_fallback(lib):
+    import finenvs_amd
+    from finenvs_amd import _lib
+
+    assert lib.fe_device_count() == 0
+    out = C.c_void_p()
+    cfg = _lib.FeConfig(4, 2, 10, 4, 1, 5, 0, 1e4, 0.01, 1.5, 0.25, 0, 0, 0, -1)
+    assert lib.fe_env_create(C.byref(cfg), 8, 8, C.byref(out)) == -2
+    assert b"no CPU path" in lib.fe_last_error()
+    with pytest.raises(RuntimeError):
+        finenvs_amd.TimeSeriesEnv(prices=[[1.0, 1, 1, 1]] * 50, day_id=[0] * 25 + [1] * 25, num_intervals=4)
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: nothing under finenvs_amd/ may reference it."""
+    bad = []
+    for root, _, files in os.walk(os.path.join(REPO, "finenvs_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(root, f), errors="ignore").read()
+                if re.search(r"\b(from|import)\s+oracle\b|fe_oracle|libfe_oracle", txt):
+                    bad.append(os.path.join(root, f))
+    assert not bad, bad

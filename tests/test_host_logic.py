@@ -1,0 +1,121 @@
+"""CPU tests of the host-side logic: CSV loader and bounds vs the reference-generated
+fixtures, shard arithmetic, the host mirror of the device RNG, the synthetic generator."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from finenvs_amd.data import loader, synthetic
+from finenvs_amd.environments.time_series_env import shard_range
+from finenvs_amd.rng import philox_u32, redraw_day
+from oracle import fe_oracle as fo
+from tests.helpers import assert_bits, load_golden
+
+CSV_CASES = [  # fixture, days, bars, seed, drop  (must mirror oracle/make_goldens.py)
+    ("tables_full.npz", 5, 40, 1234, 0.0),
+    ("tables_ragged.npz", 7, 40, 77, 0.10),
+    ("tables_skip2.npz", 6, 40, 5, 0.0),
+]
+
+
+@pytest.mark.parametrize("name,days,bars,seed,drop", CSV_CASES)
+def test_csv_loader_reproduces_reference_frames(tmp_path, name, days, bars, seed, drop):
+    g = load_golden(name)
+    prices, day_id, minute = synthetic.synthetic_series(days, 1, bars, seed, drop)
+    assert_bits(prices, g["series_prices"], "generator is deterministic")
+    d = tmp_path / "data" / "SYN"
+    synthetic.write_csv(str(d / "dummy.csv"), prices, day_id, minute, 0, premarket_rows=2)
+    path = loader.find_file_by_key(loader.get_data_dir_name(str(d)), loader.determine_file_key("dummy"))
+    p2, d2, sec = loader.read_csv_series(path)
+    assert_bits(p2, g["ref_dataset"], "market-hours rows (premarket rows filtered out)")
+    assert sec.min() >= 9 * 3600 + 30 * 60 and sec.max() <= 15 * 3600 + 59 * 60
+    starts, stops, L = loader.episode_bounds(d2, int(g["W"]))
+    assert_bits(starts, g["ref_start_indices"], "starts")
+    assert_bits(stops, g["ref_stop_indices"], "stops")
+    assert L == int(g["ref_max_length"])
+
+
+def test_loader_errors_match_reference_behaviour(tmp_path):
+    with pytest.raises(Exception, match="dataset_key expected"):
+        loader.determine_file_key("nope")
+    assert loader.determine_file_key("cross_validation") == "valid"
+    d = tmp_path / "data" / "X"
+    d.mkdir(parents=True)
+    with pytest.raises(Exception, match="No file was found"):
+        loader.find_file_by_key(str(d), "train")
+    (d / "a_train.csv").write_text("")
+    (d / "b_train.csv").write_text("")
+    with pytest.raises(Exception, match="More than one file"):
+        loader.find_file_by_key(str(d), "train")
+    assert "data" in loader.get_data_dir_name("SPY") and loader.get_data_dir_name("SPY").endswith("SPY")
+    assert loader.get_data_dir_name("/x/data/SPY") == "/x/data/SPY"
+
+
+def test_portfolio_loader_inner_joins_calendars(tmp_path):
+    prices, day_id, minute = synthetic.synthetic_series(3, 2, 30, 11)
+    a = tmp_path / "data" / "A" / "dummy.csv"
+    b = tmp_path / "data" / "B" / "dummy.csv"
+    synthetic.write_csv(str(a), prices, day_id, minute, 0)
+    keep = np.ones(len(day_id), bool)
+    keep[[5, 40, 41]] = False  # asset B misses three bars
+    synthetic.write_csv(str(b), prices[keep], day_id[keep], minute[keep], 1)
+    p, d, s = loader.read_csv_portfolio([str(a), str(b)])
+    assert p.shape == (keep.sum(), 8)
+    assert_bits(p, prices[keep], "joined series")
+    assert_bits(d, day_id[keep], "day ids")
+
+
+def test_bounds_handle_unsorted_and_empty():
+    s, e, L = loader.episode_bounds(np.zeros(0, np.int64), 4)
+    assert len(s) == 0 and L == 0
+    day = np.array([3, 3, 3, 1, 1, 1, 1, 2, 2])
+    s, e, L = loader.episode_bounds(day, 2)
+    assert s.tolist() == [1, 5] and e.tolist() == [6, 8] and L == 6
+    s2, e2, L2 = fo.bounds(day, 2)
+    assert s.tolist() == s2.tolist() and e.tolist() == e2.tolist() and L == L2
+    assert loader.padding_rows(s, e, L) == [0, 2]
+
+
+def test_shard_range_partitions_exactly():
+    for n, g in [(10, 1), (10, 3), (65536, 8), (7, 8), (1_000_003, 8)]:
+        spans = [shard_range(n, r, g) for r in range(g)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(spans[i][1] == spans[i + 1][0] for i in range(g - 1))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_host_philox_mirrors_oracle():
+    lib = fo.lib()
+    for seed, ctr in [(0, 0), (99, 1), (2**63 + 5, 2**40 + 3)]:
+        assert philox_u32(seed, ctr) == lib.fo_philox_u32(C.c_uint64(seed), C.c_uint64(ctr))
+        assert redraw_day(seed, ctr, 64) == lib.fo_redraw_day(C.c_uint64(seed), C.c_uint64(ctr), C.c_int64(64))
+
+
+def test_fastdiv_formula_used_by_the_kernel():
+    """Granlund-Montgomery constants of csrc/fe_env.hip:make_fastdiv, checked in Python."""
+    rng = np.random.default_rng(0)
+
+    def make(d):
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        m = ((1 << 32) * ((1 << l) - d)) // d + 1
+        return m & 0xFFFFFFFF, min(l, 1), max(l - 1, 0)
+
+    for d in [1, 2, 3, 5, 7, 30, 64, 150, 160, 975, 9600, 29250, 2**24, 2**31 - 1, 2**31 + 11]:
+        m, s1, s2 = make(d)
+        ns = np.concatenate([rng.integers(0, 2**32, 2000, dtype=np.uint64), np.array([0, 1, d - 1, d, d + 1, 2**32 - 1], dtype=np.uint64)])
+        for n in ns.tolist():
+            t = (m * n) >> 32
+            q = (t + (((n - t) & 0xFFFFFFFF) >> s1)) >> s2
+            assert q == n // d, (d, n)
+
+
+def test_synthetic_generator_spec():
+    p, day, minute = synthetic.synthetic_series(3, 2, 390)
+    assert p.shape == (1170, 8) and minute.min() == 570 and minute.max() == 959
+    assert np.all(p[:, 1] >= np.maximum(p[:, 0], p[:, 3]) - 1e-4) and np.all(p[:, 2] <= np.minimum(p[:, 0], p[:, 3]) + 1e-4)
+    assert abs(p[0, 0] - 100) < 1 and abs(p[0, 4] - 110) < 1
+    assert np.array_equal(np.round(p, 4), p)
