@@ -8,10 +8,12 @@
 //            delta, six-stage trade, margin checks, reward, done      TSE:298-421,447-496
 //   phase 1b one lane per env: OR of sleeve dones, liquidation fee, reward sum,
 //            evaluate-mode bookkeeping, eval-env redraw                TSE:288-289,498-536
-//   phase 2  the whole workgroup streams the tile's observations: the
-//            (W, 4A) log-return window is copied from the L2/MALL-resident
-//            table into the (W, 5A) observation with the position feature
-//            spliced in, as full 16-byte-per-lane coalesced stores     TSE:423-445
+//   phase 2  the whole workgroup streams the tile's observations: each wavefront
+//            loads 32-byte (O,H,L,C log-return) tuples of the (W, 4A) window from
+//            the L2/MALL-resident table with coalesced 16-byte loads, lays them
+//            out as 5-tuples (+ position feature) in a wave-private LDS image,
+//            reads the image back linearly (ds_read_b128) and writes the
+//            (W, 5A) observation as full 1-KiB-per-instruction stores  TSE:423-445
 //
 // A workgroup (256 threads = 4 wavefronts of 64) owns a TILE of EB consecutive
 // envs; tiles are grid-strided.  The observation of a tile is one contiguous
@@ -96,7 +98,7 @@ struct Params {
     int32_t W, A, EB;
     int32_t evaluate, redraw_mode;
     uint32_t env_elems;  // W * 5 * A, observation elements per env
-    FastDiv div_chunks;  // by chunks per env
+    FastDiv div_WA;  // by tuples per env (W * A)
     FastDiv div_A;
     float scale32, ms32, c32, imr32, S32;
     double comm, imr, one_mmr, S;
@@ -227,7 +229,12 @@ struct alignas(sizeof(OT) * VEC) Pack {
     OT v[VEC];
 };
 
+// Tuples one wavefront turns per phase-2 iteration: 5120 bytes of observation = five full
+// 1-KiB store instructions (128 f64 tuples of 40 B, or 256 f32 tuples of 20 B).
+constexpr int kStageBytes = 5120;
+
 // LDS carve-up for a tile of EB envs x A assets (S = EB*A sleeves):
+//   stage[4][5120 B] wave-private 5-tuple images (phase 2)
 //   int64 src[EB]  element offset of the window's first row in the LR table
 //   double pos[S]  position feature per sleeve
 //   double rew[S]  sleeve reward before the liquidation fee   (A > 1 only)
@@ -236,7 +243,7 @@ struct alignas(sizeof(OT) * VEC) Pack {
 //   int    any[EB] env-level done                              (A > 1 only)
 __host__ __device__ inline size_t lds_bytes(int EB, int A) {
     size_t S = (size_t)EB * A;
-    size_t b = (size_t)EB * 8 + S * 8;
+    size_t b = 4 * (size_t)kStageBytes + (size_t)EB * 8 + S * 8;
     if (A > 1) b += S * 8 + S * 4 + S * 4 + (size_t)EB * 4;
     return (b + 15) & ~(size_t)15;
 }
@@ -247,7 +254,7 @@ __global__ __launch_bounds__(kBlock) void fe_env_kernel(const Params p) {
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
     const int S = EB * A;
-    int64_t *s_src = reinterpret_cast<int64_t *>(smem);
+    int64_t *s_src = reinterpret_cast<int64_t *>(smem + 4 * kStageBytes);
     double *s_pos = reinterpret_cast<double *>(s_src + EB);
     double *s_rew = s_pos + S;
     float *s_shr = reinterpret_cast<float *>(s_rew + S);
@@ -261,7 +268,11 @@ __global__ __launch_bounds__(kBlock) void fe_env_kernel(const Params p) {
     const int W = p.W;
     const int64_t L = p.L;
     const uint32_t env_elems = p.env_elems;
-    const uint32_t chunks = env_elems / VEC;
+    const uint32_t WA = (uint32_t)W * (uint32_t)A;  // 32-byte table tuples per env
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int TPI = kStageBytes / (5 * (int)sizeof(OT));  // tuples per wave iteration
+    constexpr int G = TPI / 64;                                // tuples per lane per iteration
+    OT *stage = reinterpret_cast<OT *>(smem + wave * kStageBytes);
 
     for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
         const int64_t n0 = tile * EB;
@@ -361,29 +372,45 @@ __global__ __launch_bounds__(kBlock) void fe_env_kernel(const Params p) {
         }
         if constexpr (SINGLE || RESET_ONLY) __syncthreads();
 
-        // ---------------- phase 2: flat coalesced observation stream ----------------
+        // ---------------- phase 2: observation stream through a wave-private LDS transpose ----------------
         {
-            const uint32_t total = (uint32_t)ebt * chunks;
-            Pack<OT, VEC> *dst = reinterpret_cast<Pack<OT, VEC> *>(reinterpret_cast<OT *>(p.obs) +
-                                                                    n0 * (int64_t)env_elems);
-#pragma unroll 4
-            for (uint32_t g = tid; g < total; g += kBlock) {
-                const uint32_t ee = fdiv(g, p.div_chunks);
-                const uint32_t c = g - ee * chunks;
-                const double *src = p.LR + s_src[ee];
-                const double *posr = s_pos + ee * A;
-                Pack<OT, VEC> out;
+            const uint32_t tuples = (uint32_t)ebt * WA;
+            OT *dst = reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)env_elems;
+            for (uint32_t base = wave * TPI; base < tuples; base += 4 * TPI) {
+                double4 v[G];
+                double pz[G];
 #pragma unroll
-                for (int i = 0; i < VEC; ++i) {
-                    const uint32_t el = c * VEC + i;
-                    const uint32_t t = el / 5u;       // (row j, asset a) tuple index
-                    const uint32_t k = el - 5u * t;   // 0..3 log-returns, 4 position
-                    const double x = src[4u * t + (k < 4u ? k : 3u)];
-                    const uint32_t aa = SINGLE ? 0u : t - fdiv(t, p.div_A) * (uint32_t)A;
-                    const double pz = posr[aa];
-                    out.v[i] = (OT)(k < 4u ? x : pz);
+                for (int gi = 0; gi < G; ++gi) {
+                    const uint32_t t = base + gi * 64 + lane;
+                    const uint32_t tc = t < tuples ? t : tuples - 1;  // tail lanes re-read the last tuple
+                    const uint32_t ee = fdiv(tc, p.div_WA);           // env within the tile
+                    const uint32_t r = tc - ee * WA;                  // (row j, asset a) = r / A, r % A
+                    const uint32_t aa = SINGLE ? 0u : r - fdiv(r, p.div_A) * (uint32_t)A;
+                    v[gi] = *reinterpret_cast<const double4 *>(p.LR + s_src[ee] + 4u * r);
+                    pz[gi] = s_pos[ee * A + aa];
                 }
-                dst[g] = out;
+#pragma unroll
+                for (int gi = 0; gi < G; ++gi) {
+                    OT *w = stage + (gi * 64 + lane) * 5;
+                    w[0] = (OT)v[gi].x; w[1] = (OT)v[gi].y; w[2] = (OT)v[gi].z; w[3] = (OT)v[gi].w;
+                    w[4] = (OT)pz[gi];
+                }
+                // the image is private to this wavefront: order its LDS writes before the reads below
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                const uint32_t left = tuples - base;
+                const uint32_t nvalid = (left < (uint32_t)TPI ? left : (uint32_t)TPI) * 5u / VEC;  // packs to store
+                const Pack<OT, VEC> *rd = reinterpret_cast<const Pack<OT, VEC> *>(stage);
+                Pack<OT, VEC> *o = reinterpret_cast<Pack<OT, VEC> *>(dst + (size_t)base * 5u);
+                constexpr int kStores = TPI * 5 / VEC / 64;  // 5 full-width store instructions at 16 B/lane
+#pragma unroll
+                for (int i = 0; i < kStores; ++i) {
+                    const uint32_t c = (uint32_t)lane + 64u * i;
+                    if (c < nvalid) o[c] = rd[c];
+                }
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();  // reads done before the next iteration overwrites the image
             }
         }
         __syncthreads();  // LDS is reused by the next tile
@@ -482,30 +509,22 @@ struct fe_env {
     bool bound;
 };
 
+// The kernel instantiation a given env dispatches to (shared by launch and occupancy query).
+template <bool RESET_ONLY>
+static const void *kernel_for(bool f32, int vec, bool single) {
+#define FE_PICK(OT, VEC) \
+    (single ? (const void *)fe_env_kernel<OT, VEC, true, RESET_ONLY> : (const void *)fe_env_kernel<OT, VEC, false, RESET_ONLY>)
+    if (f32) return vec == 4 ? FE_PICK(float, 4) : (vec == 2 ? FE_PICK(float, 2) : FE_PICK(float, 1));
+    return vec == 2 ? FE_PICK(double, 2) : FE_PICK(double, 1);
+#undef FE_PICK
+}
+
 template <bool RESET_ONLY>
 static int launch_env(fe_env *env, hipStream_t st) {
-    const Params &p = env->p;
-    const bool f32 = env->cfg.obs_is_f32 != 0;
-    const bool single = p.A == 1;
-    dim3 g(env->grid), b(kBlock);
-    const size_t lds = env->lds;
-#define FE_LAUNCH(OT, VEC)                                                                       \
-    do {                                                                                         \
-        if (single)                                                                              \
-            hipLaunchKernelGGL((fe_env_kernel<OT, VEC, true, RESET_ONLY>), g, b, lds, st, p);     \
-        else                                                                                     \
-            hipLaunchKernelGGL((fe_env_kernel<OT, VEC, false, RESET_ONLY>), g, b, lds, st, p);    \
-    } while (0)
-    if (f32) {
-        if (env->vec == 4) FE_LAUNCH(float, 4);
-        else if (env->vec == 2) FE_LAUNCH(float, 2);
-        else FE_LAUNCH(float, 1);
-    } else {
-        if (env->vec == 2) FE_LAUNCH(double, 2);
-        else FE_LAUNCH(double, 1);
-    }
-#undef FE_LAUNCH
-    hipError_t he = hipGetLastError();
+    Params p = env->p;
+    void *args[] = {&p};
+    hipError_t he = hipLaunchKernel(kernel_for<RESET_ONLY>(env->cfg.obs_is_f32 != 0, env->vec, p.A == 1),
+                                    dim3(env->grid), dim3(kBlock), args, env->lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");
     return FE_OK;
 }
@@ -554,26 +573,44 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
     env->cfg = *cfg;
     env->bound = false;
     const int A = cfg->A;
-    // tile: as many envs as fit one sleeve per lane, but keep >= ~8 tiles per CU in flight
-    const int64_t want_tiles = (int64_t)prop.multiProcessorCount * 8;
-    int64_t EB = kBlock / A;
-    if (EB < 1) EB = 1;
-    const char *ov = getenv("FE_TILE_ENVS");
-    if (ov && atoi(ov) > 0) {
-        EB = atoi(ov);
-        if (EB * A > kBlock) EB = kBlock / A > 0 ? kBlock / A : 1;
-    } else {
-        int64_t by_n = cfg->N / want_tiles;
-        if (by_n < 1) by_n = 1;
-        if (EB > by_n) EB = by_n;
-    }
     const int elem_bytes = cfg->obs_is_f32 ? 4 : 8;
     int vec = 16 / elem_bytes;
     while (vec > 1 && env_elems % vec != 0) vec /= 2;
     env->vec = vec;
+    // How many workgroups the chip holds at once for this kernel variant (registers + LDS).
+    const int64_t cap = kBlock / A > 0 ? kBlock / A : 1;  // one sleeve per lane in phase 1
+    int per_cu = 0;
+    he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_for<false>(cfg->obs_is_f32 != 0, vec, A == 1),
+                                                      kBlock, lds_bytes((int)cap, A));
+    if (he != hipSuccess) {
+        delete env;
+        return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+    }
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    int64_t resident = (int64_t)prop.multiProcessorCount * per_cu;
+    if (resident > 8) resident -= resident % 8;  // keeps tile % 8 (the XCD label) constant per workgroup
+    // Tile = EB consecutive envs.  Pick the largest EB that fills whole rounds of the resident
+    // grid (equal work per workgroup, no straggler round); tiny problems fall back to EB = 1.
+    int64_t EB = 1;
+    const char *ov = getenv("FE_TILE_ENVS");
+    if (ov && atoi(ov) > 0) {
+        EB = atoi(ov) < cap ? atoi(ov) : cap;
+    } else {
+        double best = -1.0;
+        for (int64_t eb = cap; eb >= 1; --eb) {
+            const int64_t tiles = (cfg->N + eb - 1) / eb;
+            if (tiles * 10 < resident * 9 && eb > 1) continue;  // would leave CUs idle
+            const int64_t rounds = (tiles + resident - 1) / resident;
+            const double eff = (double)tiles / (double)(rounds * resident);
+            if (eff > best + 1e-9) { best = eff; EB = eb; }
+            if (eff >= 0.97) break;
+        }
+    }
     const int64_t num_tiles = (cfg->N + EB - 1) / EB;
-    int64_t grid = num_tiles < want_tiles ? num_tiles : want_tiles;
-    if (grid > 8) grid -= grid % 8;  // keep the tile -> XCD label stable across grid strides
+    int64_t grid = num_tiles < resident ? num_tiles : resident;
+    const char *gv = getenv("FE_GRID");
+    if (gv && atoi(gv) > 0) grid = atoi(gv);
     env->grid = (int)grid;
     env->lds = lds_bytes((int)EB, A);
 
@@ -589,7 +626,7 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
     p.evaluate = cfg->evaluate ? 1 : 0;
     p.redraw_mode = cfg->redraw_mode;
     p.env_elems = (uint32_t)env_elems;
-    p.div_chunks = make_fastdiv((uint32_t)(env_elems / vec));
+    p.div_WA = make_fastdiv((uint32_t)((int64_t)cfg->W * cfg->A));
     p.div_A = make_fastdiv((uint32_t)A);
     p.scale32 = (float)((double)cfg->max_shares + 0.5);
     p.ms32 = (float)cfg->max_shares;
