@@ -590,23 +590,14 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
     if (per_cu > 8) per_cu = 8;
     int64_t resident = (int64_t)prop.multiProcessorCount * per_cu;
     if (resident > 8) resident -= resident % 8;  // keeps tile % 8 (the XCD label) constant per workgroup
-    // Tile = EB consecutive envs.  Pick the largest EB that fills whole rounds of the resident
-    // grid (equal work per workgroup, no straggler round); tiny problems fall back to EB = 1.
-    int64_t EB = 1;
+    // Tile = EB consecutive envs.  Aim for ~8/3 tiles per resident workgroup: measured on
+    // MI355X (tools/sweep_tiles.py, 64k envs) a few short tiles per workgroup beat one long
+    // tile (workgroups drift apart, so phase 1 of one hides under phase 2 of its CU-mates).
+    int64_t EB = (3 * cfg->N + 4 * resident) / (8 * resident);
+    if (EB < 1) EB = 1;
+    if (EB > cap) EB = cap;
     const char *ov = getenv("FE_TILE_ENVS");
-    if (ov && atoi(ov) > 0) {
-        EB = atoi(ov) < cap ? atoi(ov) : cap;
-    } else {
-        double best = -1.0;
-        for (int64_t eb = cap; eb >= 1; --eb) {
-            const int64_t tiles = (cfg->N + eb - 1) / eb;
-            if (tiles * 10 < resident * 9 && eb > 1) continue;  // would leave CUs idle
-            const int64_t rounds = (tiles + resident - 1) / resident;
-            const double eff = (double)tiles / (double)(rounds * resident);
-            if (eff > best + 1e-9) { best = eff; EB = eb; }
-            if (eff >= 0.97) break;
-        }
-    }
+    if (ov && atoi(ov) > 0) EB = atoi(ov) < cap ? atoi(ov) : cap;
     const int64_t num_tiles = (cfg->N + EB - 1) / EB;
     int64_t grid = num_tiles < resident ? num_tiles : resident;
     const char *gv = getenv("FE_GRID");

@@ -1,0 +1,87 @@
+"""World-size-2 rehearsal of the multi-GPU path on CPU (gloo): contiguous env shards, eval env on the
+last rank, one packed all-gather of the compact trajectory fields per chunk.  (On MI355X the same code
+runs with backend "nccl" = RCCL; bench.py --gpus N exercises it.)"""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from finenvs_amd.environments.time_series_env import shard_range
+from finenvs_amd.trajectory import TrajectoryBuffer
+
+T, N_TOTAL, A = 5, 14, 3
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _fill(buf, lo, n):
+    """Deterministic per-(step, global env) values so any rank can predict any shard."""
+    for t in range(T):
+        gidx = torch.arange(lo, lo + n, dtype=torch.float64)
+        actions = (gidx.unsqueeze(1) * 10 + torch.arange(A) + 1000 * t).float()
+        rewards = gidx * 0.5 - t
+        dones = ((gidx.long() + t) % 3 == 0).int()
+        buf.store(actions, rewards, dones)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(N_TOTAL, rank, world)
+        n = hi - lo
+        buf = TrajectoryBuffer(T, n, A, device="cpu")
+        _fill(buf, lo, n)
+        assert buf.full()
+        actions, rewards, dones, _ = buf.all_gather()
+        ok = True
+        for r in range(world):
+            l2, h2 = shard_range(N_TOTAL, r, world)
+            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu")
+            _fill(ref, l2, h2 - l2)
+            ok &= torch.equal(actions[r], ref.actions) and torch.equal(rewards[r], ref.rewards) and torch.equal(dones[r], ref.dones)
+        # the eval env (last global env) is owned by the last rank only
+        owns_eval = hi == N_TOTAL
+        ok &= owns_eval == (rank == world - 1)
+        # a step-time barrier + max-over-ranks reduction like bench.py's
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ok &= float(t) == world
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_trajectory_all_gather_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(0, True), (1, True)]
+
+
+def test_shards_cover_days_like_the_single_process_env():
+    """env n -> day n mod D must not depend on how many ranks there are."""
+    D, N = 6, 50
+    single = np.arange(N) % D
+    for world in (2, 3, 8):
+        parts = []
+        for r in range(world):
+            lo, hi = shard_range(N, r, world)
+            parts.append(np.arange(lo, hi) % D)
+        assert np.array_equal(np.concatenate(parts), single)
