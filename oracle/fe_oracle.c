@@ -122,6 +122,10 @@ int64_t fo_bounds(const int64_t *day_id, int64_t T, int32_t W, int64_t *starts, 
 
 #define FO_MAX_ASSETS 256
 
+/* torch.relu lets a NaN through (clamp_min semantics) */
+static inline float relu32(float x) { return x > 0.0f ? x : (x != x ? x : 0.0f); }
+static inline double relu64(double x) { return x > 0.0 ? x : (x != x ? x : 0.0); }
+
 /* ---- a3: TSE:298-302 ---- */
 static inline float share_change(const fo_config *c, float action) {
     float scaled = action * (float)((double)c->max_shares + 0.5);
@@ -156,8 +160,7 @@ static inline void sleeve_step(const fo_config *c, float action, const double ba
     float neg = sc > 0.0f ? 0.0f : sc;
 
     /* 1 sell long, TSE:353-361 */
-    float nl = lng + neg;
-    nl = nl > 0.0f ? nl : 0.0f;
+    float nl = relu32(lng + neg);
     float sell = lng - nl;
     neg += sell;
     comm += sell * c32;
@@ -165,8 +168,7 @@ static inline void sleeve_step(const fo_config *c, float action, const double ba
     lng = nl;
 
     /* 2 buy back short, TSE:367-383 */
-    float ns = sht - pos;
-    ns = ns > 0.0f ? ns : 0.0f;
+    float ns = relu32(sht - pos);
     float bb = sht - ns;
     pos -= bb;
     comm += bb * c32;
@@ -201,22 +203,19 @@ static inline void sleeve_step(const fo_config *c, float action, const double ba
     int done = cash < 0.0f;
     double rew;
     {   /* maintenance margin check at the High */
-        double call = (double)sht * H * one_mmr - margin;
-        call = call > 0.0 ? call : 0.0;
+        double call = relu64((double)sht * H * one_mmr - margin);
         cash = (float)((double)cash - call);
         margin += call;
         done |= cash < 0.0f;
         rew = -call;
     }
     {   /* margin release at the Low */
-        double rel = margin - (double)sht * Lo * imr;
-        rel = rel > 0.0 ? rel : 0.0;
+        double rel = relu64(margin - (double)sht * Lo * imr);
         margin -= rel;
         cash = (float)((double)cash + rel);
     }
     {   /* maintenance margin check at the Close */
-        double call = (double)sht * C * one_mmr - margin;
-        call = call > 0.0 ? call : 0.0;
+        double call = relu64((double)sht * C * one_mmr - margin);
         cash = (float)((double)cash - call);
         margin += call;
         done |= cash < 0.0f;

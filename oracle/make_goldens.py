@@ -163,6 +163,12 @@ def rollout(env, T, action_seed=7, action_kind="uniform", stop_on_returns=False,
             a = torch.where(torch.rand((N, 1), generator=g) < 0.5, -1.0, 1.0) * torch.ones((N, 1))
             hold = torch.rand((N, 1), generator=g) < 0.6
             a = torch.where(hold, torch.zeros_like(a), a)
+        elif action_kind == "edge":
+            a = torch.rand((N, 1), generator=g) * 2 - 1
+            specials = [float("nan"), float("inf"), float("-inf"), 7.5, -123.0, -0.0, 1e-30, 0.0909090909]
+            if t % 9 == 4:
+                for k, sp in enumerate(specials):
+                    a[(t + 3 * k) % N, 0] = sp
         else:
             raise ValueError(action_kind)
         a = a.float()
@@ -292,6 +298,12 @@ def main():
     env, _ = make_env("OIH", 32)
     roll = rollout(env, 700, full_obs=False)
     save_rollout("rollout_oih.npz", env, roll, {"torch_seed": np.int64(2024)})
+
+    # edge-case actions: NaN, +-inf, out-of-range, -0.0 (a diverged policy must not crash or desync parity)
+    env, _ = make_env("SYN_roll", 8, evaluate=True, starting_balance=3000)
+    scale_env(env, 24)
+    roll = rollout(env, 90, action_seed=77, action_kind="edge")
+    save_rollout("rollout_edge_actions.npz", env, roll)
 
     # ---------------- multi-asset sleeve contract: A reference envs side by side ----------------
     A = 3

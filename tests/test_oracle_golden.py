@@ -87,7 +87,7 @@ def test_evaluate_rollouts_emit_reference_returns(name):
 
 
 @pytest.mark.parametrize("name", ["rollout_stress_60.npz", "rollout_stress_150.npz", "rollout_stress_400.npz",
-                                  "rollout_stress_1500.npz", "rollout_econ.npz"])
+                                  "rollout_stress_1500.npz", "rollout_econ.npz", "rollout_edge_actions.npz"])
 def test_stress_rollouts(name):
     g = load_golden(name)
     _replay(g, name)
