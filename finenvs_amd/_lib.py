@@ -48,6 +48,8 @@ SIGNATURES = {
     "fe_build_tables": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "fe_traj_store": (C.c_int, [_i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_traj_returns": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.c_double, _vp, _vp, _vp]),
+    "fe_csv_count_lines": (_i64, [C.c_char_p]),
+    "fe_csv_read": (_i64, [C.c_char_p, _i64, _i32, _vp, _vp, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

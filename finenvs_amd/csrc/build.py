@@ -13,7 +13,7 @@ import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
-SOURCES = ["fe_env.hip"]
+SOURCES = ["fe_env.hip", "fe_csv.cpp"]
 LIB = os.path.join(HERE, "libfinenvs_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [

@@ -1,0 +1,176 @@
+// fe_csv.cpp -- native CSV reader for the reference's bar files.
+//
+// Replaces read_data + force_market_hours of the reference
+// (finenvs/environments/time_series_env.py:80-91: pandas.read_csv, a Datetime index,
+// between_time("9:30", "15:59")) with one pass over an mmap of the file:
+//   row = Date,Time,Open,High,Low,Close,Volume    (finenvs/data/README.md:7-9)
+// Date is an opaque key ("2022-04-01" and "01/02/1998" both occur in the reference's
+// fixtures); Time is HH:MM[:SS]; Volume is dropped (TSE:170).
+//
+// Numbers: std::from_chars (correctly rounded).  The reference parses with pandas' default
+// converter ("high" = precise_xstrtod in pandas >= 1.2; 2.3.3 here), which is also correctly
+// rounded for <= 15 significant digits and |decimal exponent| <= 22 -- every price file is in
+// that regime; tests/test_csv_native.py pins the equality against pandas.
+//
+// Host-side code: all pointers are HOST pointers.  No HIP calls here.
+#include <fcntl.h>
+#include <stdarg.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <charconv>
+#include <unordered_map>
+
+#include "finenvs_amd.h"
+
+extern "C" int fe_set_error(int code, const char *fmt, ...);  // fe_env.hip
+
+namespace {
+
+struct Mapped {
+    const char *p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    bool ok = false;
+    explicit Mapped(const char *path) {
+        fd = open(path, O_RDONLY);
+        if (fd < 0) return;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return;
+        n = (size_t)st.st_size;
+        if (n == 0) {
+            ok = true;
+            return;
+        }
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return;
+        p = (const char *)m;
+        ok = true;
+    }
+    ~Mapped() {
+        if (p) munmap((void *)p, n);
+        if (fd >= 0) close(fd);
+    }
+};
+
+inline uint64_t fnv1a(const char *b, const char *e) {
+    uint64_t h = 1469598103934665603ull;
+    for (; b < e; ++b) h = (h ^ (unsigned char)*b) * 1099511628211ull;
+    return h;
+}
+
+inline const char *trim_l(const char *b, const char *e) {
+    while (b < e && (*b == ' ' || *b == '\t')) ++b;
+    return b;
+}
+inline const char *trim_r(const char *b, const char *e) {
+    while (e > b && (e[-1] == ' ' || e[-1] == '\t' || e[-1] == '\r')) --e;
+    return e;
+}
+
+// HH:MM[:SS] -> second of day, -1 on malformed input
+inline int64_t parse_time(const char *b, const char *e) {
+    int64_t part[3] = {0, 0, 0};
+    int k = 0, digits = 0;
+    for (const char *p = b; p < e; ++p) {
+        if (*p >= '0' && *p <= '9') {
+            part[k] = part[k] * 10 + (*p - '0');
+            ++digits;
+        } else if (*p == ':' && k < 2 && digits > 0) {
+            ++k;
+            digits = 0;
+        } else {
+            return -1;
+        }
+    }
+    if (k < 1 || digits == 0) return -1;
+    return part[0] * 3600 + part[1] * 60 + part[2];
+}
+
+constexpr int64_t kOpen = (9 * 60 + 30) * 60;   // 09:30:00, first bar kept
+constexpr int64_t kLast = (15 * 60 + 59) * 60;  // 15:59:00, last bar kept (between_time is inclusive)
+
+}  // namespace
+
+extern "C" {
+
+int64_t fe_csv_count_lines(const char *path) {
+    if (!path) return fe_set_error(FE_ERR_ARG, "fe_csv_count_lines: null path");
+    Mapped m(path);
+    if (!m.ok) return fe_set_error(FE_ERR_ARG, "fe_csv_count_lines: cannot open %s", path);
+    int64_t lines = 0;
+    const char *p = m.p, *end = m.p + m.n;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        ++lines;
+        if (!nl) break;
+        p = nl + 1;
+    }
+    return lines;
+}
+
+int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_only, double *prices,
+                    int64_t *day_id, int64_t *date_key, int64_t *second_of_day) {
+    if (!path || !prices || !day_id || !second_of_day || capacity < 0)
+        return fe_set_error(FE_ERR_ARG, "fe_csv_read: bad argument");
+    Mapped m(path);
+    if (!m.ok) return fe_set_error(FE_ERR_ARG, "fe_csv_read: cannot open %s", path);
+    std::unordered_map<uint64_t, int64_t> days;  // date key -> id in order of first appearance
+    int64_t rows = 0, line_no = 0;
+    const char *p = m.p, *end = m.p + m.n;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        ++line_no;
+        const char *lb = trim_l(p, le);
+        const char *lt = trim_r(lb, le);
+        p = nl ? nl + 1 : end;
+        if (lb == lt) continue;  // blank line
+        // split the first six fields
+        const char *fb[7], *fe_[7];
+        int nf = 0;
+        const char *q = lb;
+        while (nf < 7) {
+            const char *c = (const char *)memchr(q, ',', (size_t)(lt - q));
+            fb[nf] = trim_l(q, c ? c : lt);
+            fe_[nf] = trim_r(fb[nf], c ? c : lt);
+            ++nf;
+            if (!c) break;
+            q = c + 1;
+        }
+        if (nf < 6) return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld has %d fields, need >= 6", path, (long long)line_no, nf);
+        const int64_t sec = parse_time(fb[1], fe_[1]);
+        if (sec < 0) return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld: bad time", path, (long long)line_no);
+        if (market_hours_only && (sec < kOpen || sec > kLast)) continue;
+        if (rows >= capacity) return fe_set_error(FE_ERR_ARG, "fe_csv_read: capacity %lld too small", (long long)capacity);
+        for (int k = 0; k < 4; ++k) {
+            double v;
+            const char *b = fb[2 + k], *e = fe_[2 + k];
+            if (b < e && *b == '+') ++b;
+            auto r = std::from_chars(b, e, v);
+            if (r.ec != std::errc() || r.ptr != e)
+                return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld: bad number in column %d", path, (long long)line_no, 3 + k);
+            prices[rows * 4 + k] = v;
+        }
+        const uint64_t key = fnv1a(fb[0], fe_[0]);
+        auto it = days.find(key);
+        int64_t id;
+        if (it == days.end()) {
+            id = (int64_t)days.size();
+            days.emplace(key, id);
+        } else {
+            id = it->second;
+        }
+        day_id[rows] = id;
+        if (date_key) date_key[rows] = (int64_t)(key >> 1);
+        second_of_day[rows] = sec;
+        ++rows;
+    }
+    return rows;
+}
+
+}  // extern "C"

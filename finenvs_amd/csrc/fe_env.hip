@@ -531,6 +531,15 @@ static int launch_env(fe_env *env, hipStream_t st) {
 
 extern "C" {
 
+// shared with fe_csv.cpp (not part of the public header)
+int fe_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
 int fe_version(void) { return FE_ABI_VERSION; }
 
 const char *fe_last_error(void) { return g_err; }

@@ -5,6 +5,7 @@ time_series_env.py), re-designed:
 
 * file lookup by dataset key with the reference's error behaviour (TSE:47-73),
 * CSV rows ``Date,Time,Open,High,Low,Close,Volume`` (TSE:80-88), Volume dropped (TSE:170),
+  parsed by the native reader csrc/fe_csv.cpp (mmap, one pass; pandas only in the tests),
 * market-hours filter 09:30 <= time <= 15:59 inclusive (TSE:90-91),
 * per date, in order of first appearance: rows ``[first - W, last]``; dates whose
   backtracked start would be negative are skipped; L = longest episode (TSE:127-152).
@@ -55,13 +56,43 @@ def find_file_by_key(data_dir_name: str, key: str) -> str:
     return filenames[0]
 
 
+def _read_native(path: str, market_hours_only: bool = True):
+    """One pass over an mmap of the file in C++ (csrc/fe_csv.cpp): prices, day ids, date keys, seconds."""
+    import ctypes as C
+
+    from .. import _lib
+
+    lib = _lib.load()
+    bpath = os.fsencode(path)
+    cap = lib.fe_csv_count_lines(bpath)
+    if cap < 0:
+        _lib.check(int(cap), lib)
+    prices = np.empty((max(cap, 1), 4), dtype=np.float64)
+    day_id = np.empty(max(cap, 1), dtype=np.int64)
+    key = np.empty(max(cap, 1), dtype=np.int64)
+    sec = np.empty(max(cap, 1), dtype=np.int64)
+    rows = lib.fe_csv_read(bpath, cap, int(market_hours_only), prices.ctypes.data_as(C.c_void_p),
+                           day_id.ctypes.data_as(C.c_void_p), key.ctypes.data_as(C.c_void_p),
+                           sec.ctypes.data_as(C.c_void_p))
+    if rows < 0:
+        _lib.check(int(rows), lib)
+    return prices[:rows].copy(), day_id[:rows].copy(), key[:rows].copy(), sec[:rows].copy()
+
+
 def read_csv_series(path: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
     """One instrument: (prices (T,4) f64 O,H,L,C; day_id (T,) i64; second-of-day (T,) i64),
     already restricted to market hours.  day_id numbers dates by first appearance."""
-    import pandas as pd  # host-side parsing only
+    prices, day_id, _, sec = _read_native(path)
+    return prices, day_id, sec
+
+
+def read_csv_series_pandas(path: str) -> Tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """The same through pandas, the reference's own parser (TSE:80-91).  Kept as the
+    cross-check of the native reader in tests; the product path does not use it."""
+    import pandas as pd
 
     df = pd.read_csv(path, names=["Date", "Time", "Open", "High", "Low", "Close", "Volume"], dtype={"Date": str, "Time": str})
-    t = df["Time"].str.split(":", expand=True).astype(np.int64)
+    t = df["Time"].str.strip().str.split(":", expand=True).fillna("0").astype(np.int64)
     sec = t[0].values * 3600 + t[1].values * 60 + (t[2].values if t.shape[1] > 2 else 0)
     keep = (sec >= OPEN_SECONDS) & (sec <= LAST_SECONDS)
     dates = df["Date"].values[keep]
@@ -77,24 +108,22 @@ def read_csv_portfolio(paths: Sequence[str]) -> Tuple[np.ndarray, np.ndarray, np
     date + time, in the first file's order), columns 4a..4a+3 = asset a."""
     if len(paths) == 1:
         return read_csv_series(paths[0])
-    import pandas as pd
-
-    frames = []
-    for a, p in enumerate(paths):
-        df = pd.read_csv(p, names=["Date", "Time", "Open", "High", "Low", "Close", "Volume"], dtype={"Date": str, "Time": str})
-        df = df.drop(columns=["Volume"]).set_index(["Date", "Time"])
-        df.columns = [f"{c}{a}" for c in df.columns]
-        frames.append(df)
-    joined = frames[0].join(frames[1:], how="inner").reset_index()
-    t = joined["Time"].str.split(":", expand=True).astype(np.int64)
-    sec = t[0].values * 3600 + t[1].values * 60 + (t[2].values if t.shape[1] > 2 else 0)
-    keep = (sec >= OPEN_SECONDS) & (sec <= LAST_SECONDS)
-    dates = joined["Date"].values[keep]
-    _, first_pos, inv = np.unique(dates, return_index=True, return_inverse=True)
-    order = np.argsort(np.argsort(first_pos))
-    cols = [c for c in joined.columns if c not in ("Date", "Time")]
-    prices = np.ascontiguousarray(joined[cols].values[keep], dtype=np.float64)
-    return prices, order[inv].astype(np.int64), sec[keep].astype(np.int64)
+    parts = [_read_native(p) for p in paths]
+    # join key: (date text hash, second of day); a day has < 86400 seconds
+    jk = [key * 131072 + sec for _, _, key, sec in parts]
+    common = jk[0]
+    for k in jk[1:]:
+        common = common[np.isin(common, k)]
+    cols = []
+    for (prices, _, _, _), k in zip(parts, jk):
+        order = np.argsort(k, kind="stable")
+        pos = order[np.searchsorted(k[order], common)]
+        cols.append(prices[pos])
+    sel = np.isin(jk[0], common)
+    day0, sec0 = parts[0][1][sel], parts[0][3][sel]
+    _, first_pos, inv = np.unique(day0, return_index=True, return_inverse=True)
+    rank = np.argsort(np.argsort(first_pos))
+    return np.ascontiguousarray(np.concatenate(cols, axis=1)), rank[inv].astype(np.int64), sec0
 
 
 def episode_bounds(day_id: np.ndarray, num_intervals: int) -> Tuple[np.ndarray, np.ndarray, int]:

@@ -147,6 +147,20 @@ int fe_traj_returns(const double *rewards, const int32_t *dones, const float *va
                     const float *last_values, int64_t T, int64_t N, double gamma, float *returns,
                     float *advantages, void *stream);
 
+/*
+ * Native CSV reader: replaces read_data + force_market_hours (TSE:80-91).
+ * Rows are Date,Time,Open,High,Low,Close,Volume.  ALL POINTERS HERE ARE HOST POINTERS.
+ * fe_csv_count_lines gives an upper bound for `capacity`.  fe_csv_read fills
+ * prices (rows, 4) f64 = O,H,L,C, day_id (rows) = index of the row's date in order of
+ * first appearance, date_key (rows; may be NULL) = 63-bit FNV-1a hash of the date text
+ * (equal text <=> equal key, usable to join files), second_of_day (rows); with
+ * market_hours_only != 0 only rows with 09:30:00 <= time <= 15:59:00 are kept.
+ * Both return the row count, or a negative FE_ERR_* code.
+ */
+int64_t fe_csv_count_lines(const char *path);
+int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_only, double *prices,
+                    int64_t *day_id, int64_t *date_key, int64_t *second_of_day);
+
 #ifdef __cplusplus
 }
 #endif
