@@ -102,11 +102,18 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
     import torch.distributed as dist
 
+    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on device 0 + gloo
+    if os.environ.get("FE_BENCH_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("FE_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(dev))
+        else:
+            dist.init_process_group(backend)
 
     import finenvs_amd
     from finenvs_amd.trajectory import TrajectoryBuffer
@@ -124,7 +131,6 @@ def main():
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
     traj = TrajectoryBuffer(TRAJ_T, N, A, device=dev) if world > 1 else None
-    gathered = torch.empty((world, traj._nbytes), dtype=torch.uint8, device=dev) if traj else None
 
     def one_step(i):
         a = actions[i % 8]
@@ -132,8 +138,7 @@ def main():
         if traj is not None:
             traj.store(a, rew, done)
             if traj.full():
-                traj.all_gather(out=gathered)
-                traj.clear()
+                traj.all_gather_async()  # overlaps the next TRAJ_T steps; waited for before reuse
         return obs
 
     roll = None
@@ -151,6 +156,8 @@ def main():
     run_steps(args.warmup)
 
     def fence():
+        if traj is not None:
+            traj.drain()  # outstanding gathers belong to the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -219,7 +226,8 @@ def main():
                        "obs_buffers": obs_buffers, "eval_redraw": args.redraw,
                        "launch_mode": "hipGraph x8 steps" if args.graph else "eager, one launch per step",
                        "launch": env.launch_info(),
-                       "trajectory_all_gather_every": TRAJ_T if world > 1 else None},
+                       "trajectory_all_gather_every": TRAJ_T if world > 1 else None,
+                       "collective_backend": (backend if world > 1 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
                          "kernel": "fe_env_kernel (fused step)", "kernel_ms": kern_ms,

@@ -87,6 +87,9 @@ struct Params {
     uint8_t *terminated;
     float *ep_ret;
     unsigned long long *counters;
+    float *run_ret;      // optional episode statistics (fe_env_bind_stats): running return per env
+    double *stat_acc;    // [0] finished training episodes, [1] sum of their returns, [2] sum of squares
+    float *stat_eval;    // [0] return of the eval env's last finished episode, [1] how many it finished
     const float *actions;
     void *obs;
     double *rew;
@@ -358,6 +361,21 @@ __global__ __launch_bounds__(kBlock) void fe_env_kernel(const Params p) {
                 }
                 p.rew[n] = rew;
                 p.done[n] = any ? 1 : 0;
+                if (p.run_ret) {  // PPO_agent.py:120-132 without its per-step host sync
+                    float cr = (float)((double)p.run_ret[n] + rew);
+                    if (any) {
+                        if (n == p.eval_env) {
+                            p.stat_eval[0] = cr;
+                            p.stat_eval[1] += 1.0f;
+                        } else {
+                            atomicAdd(&p.stat_acc[0], 1.0);
+                            atomicAdd(&p.stat_acc[1], (double)cr);
+                            atomicAdd(&p.stat_acc[2], (double)cr * (double)cr);
+                        }
+                        cr = 0.0f;
+                    }
+                    p.run_ret[n] = cr;
+                }
             }
             if constexpr (!SINGLE) {
                 __syncthreads();
@@ -654,6 +672,21 @@ int fe_env_bind_state(fe_env *env, int64_t *env_idx, int64_t *spot0, float *cash
     p.margin = margin; p.terminated = terminated; p.ep_ret = episode_returns;
     p.counters = reinterpret_cast<unsigned long long *>(counters);
     env->bound = true;
+    return FE_OK;
+}
+
+int fe_env_bind_stats(fe_env *env, float *running_returns, double *accumulators, float *eval_return) {
+    if (!env) return fail(FE_ERR_ARG, "fe_env_bind_stats: null env");
+    if (!running_returns) {  // unbind
+        env->p.run_ret = nullptr;
+        env->p.stat_acc = nullptr;
+        env->p.stat_eval = nullptr;
+        return FE_OK;
+    }
+    if (!accumulators || !eval_return) return fail(FE_ERR_ARG, "fe_env_bind_stats: null accumulator pointer");
+    env->p.run_ret = running_returns;
+    env->p.stat_acc = accumulators;
+    env->p.stat_eval = eval_return;
     return FE_OK;
 }
 

@@ -1,0 +1,53 @@
+"""Episode statistics kept on the device.
+
+The reference's agents track, per rollout step and with a host sync each time
+(finenvs/agents/PPO/PPO_agent.py:120-132, 146-163): a running return per env, the list of
+returns of finished *training* episodes (all envs but the last), and the return of the last
+finished *evaluation* episode (the last env); at log time they report
+``len(list), mean(list), std(list)``.  ``EpisodeStats`` binds three small device buffers to
+the env; the fused step kernel updates them (atomics for the finished-episode sums) and
+``read()`` fetches the numbers with a single device-to-host copy at log time.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+
+from . import _lib
+
+
+class EpisodeStats:
+    def __init__(self, env):
+        if env.evaluate:
+            raise ValueError("EpisodeStats follows the training-mode bookkeeping of the reference's agents")
+        self.env = env
+        dev = env._dev
+        self.running_returns = torch.zeros((env.num_envs,), dtype=torch.float32, device=dev)
+        self._acc = torch.zeros((3,), dtype=torch.float64, device=dev)
+        self._eval = torch.zeros((2,), dtype=torch.float32, device=dev)
+        _lib.check(env._lib.fe_env_bind_stats(env._handle, self.running_returns.data_ptr(), self._acc.data_ptr(),
+                                              self._eval.data_ptr()))
+
+    def close(self) -> None:
+        _lib.check(self.env._lib.fe_env_bind_stats(self.env._handle, None, None, None))
+
+    def read(self, reset: bool = True) -> Dict[str, float]:
+        """One D2H copy: what PPOAgent.log_progress prints (PPO_agent.py:146-163)."""
+        acc = self._acc.cpu()
+        ev = self._eval.cpu()
+        n, s, ss = float(acc[0]), float(acc[1]), float(acc[2])
+        mean = s / n if n > 0 else float("nan")
+        var = (ss - n * mean * mean) / (n - 1) if n > 1 else float("nan")  # unbiased, as torch.std
+        out = {
+            "num_training_episodes": int(n),
+            "mean_training_return": mean,
+            "std_dev_training_return": math.sqrt(max(var, 0.0)) if n > 1 else float("nan"),
+            "evaluation_return": float(ev[0]) if ev[1] > 0 else None,
+            "num_evaluation_episodes": int(ev[1]),
+        }
+        if reset:
+            self._acc.zero_()
+            self._eval.zero_()
+        return out

@@ -27,17 +27,47 @@ class TrajectoryBuffer:
         self.T, self.N, self.A = int(num_steps), int(num_envs), int(num_assets)
         self.device = torch.device(device)
         T, N, A = self.T, self.N, self.A
-        # one allocation, three typed views: [rewards f64 | actions f32 | dones i32]
+        # one allocation per chunk, three typed views: [rewards f64 | actions f32 | dones i32];
+        # two chunks so that a chunk can be in flight on the collective stream while the next fills
         self._nbytes = T * N * 8 + T * N * A * 4 + T * N * 4
-        self._packed = torch.zeros((self._nbytes,), dtype=torch.uint8, device=self.device)
-        o1 = T * N * 8
-        o2 = o1 + T * N * A * 4
-        self.rewards = self._packed[:o1].view(torch.float64).view(T, N)
-        self.actions = self._packed[o1:o2].view(torch.float32).view(T, N, A)
-        self.dones = self._packed[o2:].view(torch.int32).view(T, N)
+        self._chunks = [torch.zeros((self._nbytes,), dtype=torch.uint8, device=self.device) for _ in range(2)]
+        self._views = [self._typed(c) for c in self._chunks]
+        self._pending = [None, None]   # outstanding collective per chunk
+        self._gathered = [None, None]  # its output buffer
+        self._cur = 0
         self.t = 0
         self._native = self.device.type == "cuda"
         self._lib = _lib.load() if self._native else None
+
+    def _typed(self, packed: torch.Tensor, lead: Tuple[int, ...] = ()):
+        T, N, A = self.T, self.N, self.A
+        o1 = T * N * 8
+        o2 = o1 + T * N * A * 4
+        flat = packed.reshape(-1, self._nbytes) if lead else packed
+        if lead:
+            G = flat.shape[0]
+            return (flat[:, o1:o2].contiguous().view(torch.float32).view(G, T, N, A),
+                    flat[:, :o1].contiguous().view(torch.float64).view(G, T, N),
+                    flat[:, o2:].contiguous().view(torch.int32).view(G, T, N))
+        return (packed[o1:o2].view(torch.float32).view(T, N, A), packed[:o1].view(torch.float64).view(T, N),
+                packed[o2:].view(torch.int32).view(T, N))
+
+    # the chunk being filled
+    @property
+    def actions(self) -> torch.Tensor:
+        return self._views[self._cur][0]
+
+    @property
+    def rewards(self) -> torch.Tensor:
+        return self._views[self._cur][1]
+
+    @property
+    def dones(self) -> torch.Tensor:
+        return self._views[self._cur][2]
+
+    @property
+    def _packed(self) -> torch.Tensor:
+        return self._chunks[self._cur]
 
     def __len__(self) -> int:
         return self.t
@@ -83,20 +113,48 @@ class TrajectoryBuffer:
 
     # ------------------------------------------------------------------ multi-GPU exchange
     def all_gather(self, group=None, out: Optional[torch.Tensor] = None):
-        """One collective: every rank receives every rank's packed chunk.
+        """One blocking collective: every rank receives every rank's packed chunk.
 
         Returns ``(actions (G, T, n, A), rewards (G, T, n), dones (G, T, n), packed)``
-        as views of the gathered byte buffer (all ranks must own the same n)."""
+        (all ranks must own the same n)."""
         import torch.distributed as dist
 
         G = dist.get_world_size(group)
         if out is None:
             out = torch.empty((G, self._nbytes), dtype=torch.uint8, device=self.device)
         dist.all_gather_into_tensor(out.view(-1), self._packed, group=group)
-        T, N, A = self.T, self.N, self.A
-        o1 = T * N * 8
-        o2 = o1 + T * N * A * 4
-        rewards = out[:, :o1].contiguous().view(torch.float64).view(G, T, N) if G > 1 else out[0, :o1].view(torch.float64).view(1, T, N)
-        actions = out[:, o1:o2].contiguous().view(torch.float32).view(G, T, N, A) if G > 1 else out[0, o1:o2].view(torch.float32).view(1, T, N, A)
-        dones = out[:, o2:].contiguous().view(torch.int32).view(G, T, N) if G > 1 else out[0, o2:].view(torch.int32).view(1, T, N)
-        return actions, rewards, dones, out
+        a, r, d = self._typed(out, lead=(G,))
+        return a, r, d, out
+
+    def all_gather_async(self, group=None) -> None:
+        """Start gathering the chunk just filled on the collective's own stream and switch to the
+        other chunk, so the exchange over xGMI overlaps the next T env steps.  ``wait_gathered``
+        returns the result; a chunk is waited for automatically before it is refilled."""
+        import torch.distributed as dist
+
+        G = dist.get_world_size(group)
+        i = self._cur
+        if self._gathered[i] is None:
+            self._gathered[i] = torch.empty((G, self._nbytes), dtype=torch.uint8, device=self.device)
+        self._pending[i] = dist.all_gather_into_tensor(self._gathered[i].view(-1), self._chunks[i], group=group,
+                                                       async_op=True)
+        self._cur = 1 - i
+        self._wait(self._cur)  # the chunk about to be refilled must have left
+        self.t = 0
+
+    def _wait(self, i: int) -> None:
+        if self._pending[i] is not None:
+            self._pending[i].wait()  # stream-level wait for NCCL/RCCL; blocks the host only for gloo
+            self._pending[i] = None
+
+    def wait_gathered(self):
+        """(actions, rewards, dones) of the most recently started gather, as (G, T, n, ...) tensors."""
+        i = 1 - self._cur
+        self._wait(i)
+        if self._gathered[i] is None:
+            raise RuntimeError("no gather has been started")
+        return self._typed(self._gathered[i], lead=(self._gathered[i].shape[0],))
+
+    def drain(self) -> None:
+        for i in (0, 1):
+            self._wait(i)

@@ -105,6 +105,17 @@ int fe_env_reset_obs(fe_env *env, void *obs, void *stream);
 int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
                 void *stream);
 
+/*
+ * Optional episode statistics fused into fe_env_step: replaces the per-step
+ * bookkeeping of the reference's agents (finenvs/agents/PPO/PPO_agent.py:120-132: running
+ * return per env, returns of finished training episodes, the eval env's return -- and its
+ * per-step .item() sync).  running_returns (N) f32; accumulators (3) f64 = {finished
+ * training episodes, sum of their returns, sum of squares}; eval_return (2) f32 = {return of
+ * the eval env's last finished episode, number it finished}.  All device pointers, caller
+ * zero-initialised; pass running_returns = NULL to unbind.
+ */
+int fe_env_bind_stats(fe_env *env, float *running_returns, double *accumulators, float *eval_return);
+
 /* env_indices[env] = day (the host half of TSE:510-513 when redraw_mode == 0). */
 int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream);
 

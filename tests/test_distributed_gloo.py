@@ -48,6 +48,20 @@ def _worker(rank, world, port, q):
             ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu")
             _fill(ref, l2, h2 - l2)
             ok &= torch.equal(actions[r], ref.actions) and torch.equal(rewards[r], ref.rewards) and torch.equal(dones[r], ref.dones)
+        # the overlapped form used by bench.py: start, keep filling the other chunk, then collect
+        buf.all_gather_async()
+        assert len(buf) == 0
+        _fill(buf, lo + 1000, n)          # the next chunk fills while the first is in flight
+        a2, r2, d2 = buf.wait_gathered()
+        for r in range(world):
+            l2, h2 = shard_range(N_TOTAL, r, world)
+            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu")
+            _fill(ref, l2, h2 - l2)
+            ok &= torch.equal(a2[r], ref.actions) and torch.equal(r2[r], ref.rewards) and torch.equal(d2[r], ref.dones)
+        buf.all_gather_async()
+        a3, r3, d3 = buf.wait_gathered()
+        ok &= float(r3[rank][0, 0]) == (lo + 1000) * 0.5
+        buf.drain()
         # the eval env (last global env) is owned by the last rank only
         owns_eval = hi == N_TOTAL
         ok &= owns_eval == (rank == world - 1)
