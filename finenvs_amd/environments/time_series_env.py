@@ -25,7 +25,6 @@ import numpy as np
 import torch
 
 from .. import _lib
-from ..base_object import BaseObject
 from ..data import loader
 from ..device_utils import set_device
 from ..rng import redraw_day
@@ -39,7 +38,7 @@ def shard_range(num_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
-class TimeSeriesEnv(BaseObject):
+class TimeSeriesEnv:
     def __init__(
         self,
         instrument_name: Union[str, Sequence[str]] = "synthetic",
@@ -248,6 +247,17 @@ class TimeSeriesEnv(BaseObject):
         self._obs_next = 0
         self._step_fn = self._lib.fe_env_step
         self._handle_v = handle.value
+
+    def print(self) -> None:
+        """Attribute dump, the reference's BaseObject.print (finenvs/base_object.py:7-9); device tensors
+        are summarised by shape and dtype instead of being copied to the host and printed."""
+        for key in sorted(vars(self)):
+            val = getattr(self, key)
+            if isinstance(val, torch.Tensor):
+                val = f"Tensor{tuple(val.shape)} {str(val.dtype).replace('torch.', '')} on {val.device}"
+            elif isinstance(val, (list, tuple)) and val and isinstance(val[0], torch.Tensor):
+                val = f"[{len(val)} x Tensor{tuple(val[0].shape)}]"
+            print(f"{key:32s} {val}")
 
     def launch_info(self) -> Dict[str, int]:
         g, b, t, l = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()

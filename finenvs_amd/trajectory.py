@@ -23,9 +23,13 @@ from . import _lib
 
 
 class TrajectoryBuffer:
-    def __init__(self, num_steps: int, num_envs: int, num_assets: int = 1, device: str = "cuda:0"):
+    def __init__(self, num_steps: int, num_envs: int, num_assets: int = 1, device: str = "cuda:0",
+                 host_rehearsal: bool = False):
         self.T, self.N, self.A = int(num_steps), int(num_envs), int(num_assets)
         self.device = torch.device(device)
+        if self.device.type != "cuda" and not host_rehearsal:
+            raise RuntimeError("TrajectoryBuffer lives in HBM; host tensors are accepted only with host_rehearsal=True, "
+                               "which exists to rehearse the all-gather plumbing over gloo (no kernels run there)")
         T, N, A = self.T, self.N, self.A
         # one allocation per chunk, three typed views: [rewards f64 | actions f32 | dones i32];
         # two chunks so that a chunk can be in flight on the collective stream while the next fills

@@ -38,14 +38,14 @@ def _worker(rank, world, port, q):
     try:
         lo, hi = shard_range(N_TOTAL, rank, world)
         n = hi - lo
-        buf = TrajectoryBuffer(T, n, A, device="cpu")
+        buf = TrajectoryBuffer(T, n, A, device="cpu", host_rehearsal=True)
         _fill(buf, lo, n)
         assert buf.full()
         actions, rewards, dones, _ = buf.all_gather()
         ok = True
         for r in range(world):
             l2, h2 = shard_range(N_TOTAL, r, world)
-            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu")
+            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu", host_rehearsal=True)
             _fill(ref, l2, h2 - l2)
             ok &= torch.equal(actions[r], ref.actions) and torch.equal(rewards[r], ref.rewards) and torch.equal(dones[r], ref.dones)
         # the overlapped form used by bench.py: start, keep filling the other chunk, then collect
@@ -55,7 +55,7 @@ def _worker(rank, world, port, q):
         a2, r2, d2 = buf.wait_gathered()
         for r in range(world):
             l2, h2 = shard_range(N_TOTAL, r, world)
-            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu")
+            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu", host_rehearsal=True)
             _fill(ref, l2, h2 - l2)
             ok &= torch.equal(a2[r], ref.actions) and torch.equal(r2[r], ref.rewards) and torch.equal(d2[r], ref.dones)
         buf.all_gather_async()

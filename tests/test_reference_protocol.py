@@ -101,3 +101,19 @@ def test_portfolio_env_from_several_instruments(tmp_path):
     single = TimeSeriesEnv(names[1], "dummy", num_intervals=10, evaluate=True)
     assert torch.equal(env.price_environments[:, :, 4:8], single.price_environments)
     assert torch.equal(env.log_return_environments[:, :, 4:8].nan_to_num(7.0), single.log_return_environments.nan_to_num(7.0))
+
+
+def test_example_rollout_loop_eager_and_graphed_agree():
+    """examples/time_series_rollout.py: the reference's loop shape with a stand-in LSTM policy;
+    the hipGraph form must produce the very same trajectory as the eager loop."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "time_series_rollout.py")
+    spec = importlib.util.spec_from_file_location("time_series_rollout", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log_e, ret_e = mod.main(envs=512, window=4, iters=30, steps=16, graph=False, hidden=16, seed=1)
+    log_g, ret_g = mod.main(envs=512, window=4, iters=30, steps=16, graph=True, hidden=16, seed=1)
+    assert log_e["num_training_episodes"] == log_g["num_training_episodes"] > 0
+    assert torch.equal(ret_e, ret_g)
