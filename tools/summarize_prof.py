@@ -59,7 +59,7 @@ with open(os.path.join(dst, f"{tag}_c{cfg}_summary.md"), "w") as f:
     f.write(f"# {tag} config {cfg}: {bench['config']['workload']}\n\n")
     f.write(f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config {cfg} --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu` (+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)\n\n")
     f.write(f"* step kernel `{short(step['Name'])}`: {step['Calls']} calls, avg {avg/1e3:.2f} us, min {float(step['MinNs'])/1e3:.2f} us, max {float(step['MaxNs'])/1e3:.2f} us ({step['Percentage']} % of GPU time)\n")
-    f.write(f"* bench.py under the profiler: {bench['value']:.4g} env-steps/s, {bench['ms_per_step']*1e3:.2f} us/step wall, HIP-event kernel interval {r['kernel_ms']*1e3:.2f} us (min {r['kernel_ms_min']*1e3:.2f})\n")
+    f.write(f"* bench.py under the profiler: {bench['value']:.4g} env-steps/s, {bench['ms_per_step']*1e3:.2f} us/step wall, HIP-event average launch interval {r['kernel_ms']*1e3:.2f} us (kernel + launch boundary, tight C-ABI loop)\n")
     f.write(f"* algorithmic bytes per launch: {B} B x {N} envs = {B*N/1e6:.1f} MB -> {B*N/avg:.0f} GB/s at the rocprof average = {B*N/avg/8000*100:.1f} % of 8 TB/s\n")
     f.write(f"* PMC (per launch): FETCH_SIZE {fetch_kb:.1f} KiB raw, WRITE_SIZE {write_kb:.1f} KiB -> HBM traffic ~ {traffic/1e6:.1f} MB ({traffic/avg:.0f} GB/s at the rocprof average)\n")
     f.write(f"* grid {meta.get('Grid_Size')} threads of 256 ({bench['config']['launch']})\n")
