@@ -318,7 +318,11 @@ __global__ __launch_bounds__(kBlock) void fe_env_kernel(const Params p) {
                     s_flg[e * A + a] = sdone ? 1 : 0;
                 }
             }
-            if (a == 0) s_src[e] = (idx * L + s0) * rs;
+            if (a == 0) {
+                // memory safety only: a well-formed state always has s0 + W <= L
+                const int64_t s0c = s0 + W <= L ? s0 : L - W;
+                s_src[e] = (idx * L + s0c) * rs;
+            }
         }
 
         // ---------------- phase 1b: one lane per env ----------------
