@@ -34,6 +34,8 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         cmd = [HIPCC] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", LIB]
+        if os.environ.get("FE_MIN_WAVES_PER_EU"):  # tuning experiments only
+            cmd.insert(1, "-DFE_MIN_WAVES_PER_EU=" + os.environ["FE_MIN_WAVES_PER_EU"])
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)

@@ -38,6 +38,11 @@
 namespace {
 
 constexpr int kBlock = 256;
+// 7 waves per SIMD = 72 VGPRs: the most the step kernel reaches without scratch spills
+// (8 spills 12-36 B/lane and measured slower); the 20 KiB LDS stage allows 7 workgroups per CU too.
+#ifndef FE_MIN_WAVES_PER_EU
+#define FE_MIN_WAVES_PER_EU 7
+#endif
 
 thread_local char g_err[512] = "";
 
@@ -252,7 +257,7 @@ __host__ __device__ inline size_t lds_bytes(int EB, int A) {
 }
 
 template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY>
-__global__ __launch_bounds__(kBlock) void fe_env_kernel(const Params p) {
+__global__ __launch_bounds__(kBlock, FE_MIN_WAVES_PER_EU) void fe_env_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
@@ -630,6 +635,14 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
     const char *ov = getenv("FE_TILE_ENVS");
     if (ov && atoi(ov) > 0) EB = atoi(ov) < cap ? atoi(ov) : cap;
     const int64_t num_tiles = (cfg->N + EB - 1) / EB;
+    // the LDS footprint depends on EB: ask again with the real size before fixing the grid
+    he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_for<false>(cfg->obs_is_f32 != 0, vec, A == 1),
+                                                      kBlock, lds_bytes((int)EB, A));
+    if (he == hipSuccess && per_cu >= 1) {
+        if (per_cu > 8) per_cu = 8;
+        resident = (int64_t)prop.multiProcessorCount * per_cu;
+        if (resident > 8) resident -= resident % 8;
+    }
     int64_t grid = num_tiles < resident ? num_tiles : resident;
     const char *gv = getenv("FE_GRID");
     if (gv && atoi(gv) > 0) grid = atoi(gv);
