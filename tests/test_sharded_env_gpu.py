@@ -1,0 +1,93 @@
+"""Sharding parity on the GPU box: two ranks (both on cuda:0, gloo for the exchange) each own a
+contiguous shard of the envs; their gathered trajectories must equal a single-process env over all
+N envs, bit for bit -- env n -> day n mod D, eval env on the last rank only, device redraw there."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+N_TOTAL, A, W, T = 1000, 2, 8, 70
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _series():
+    from finenvs_amd.data import synthetic
+
+    return synthetic.synthetic_series(5, A, 30, 21)
+
+
+def _actions(t):
+    g = torch.Generator().manual_seed(1000 + t)
+    return (torch.rand((N_TOTAL, A), generator=g) * 2 - 1).float()
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+
+    import finenvs_amd
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        prices, day_id, _ = _series()
+        env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N_TOTAL, rank=rank,
+                                        world_size=world, redraw="device", seed=77)
+        lo, hi = finenvs_amd.shard_range(N_TOTAL, rank, world)
+        assert env.num_envs == hi - lo and env.env_offset == lo and env.global_num_envs == N_TOTAL
+        buf = TrajectoryBuffer(T, env.num_envs, A, device=env.device)
+        env.reset()
+        for t in range(T):
+            a, r, d = buf.next_slot()
+            a.copy_(_actions(t)[lo:hi].to(env.device))
+            env.step(a, rewards_out=r, dones_out=d)
+        buf.all_gather_async()
+        acts, rews, dones = buf.wait_gathered()
+        torch.cuda.synchronize()
+        q.put((rank, rews.cpu().numpy(), dones.cpu().numpy(), acts.cpu().numpy(), env.env_indices.cpu().numpy()))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_sharded_ranks_equal_one_unsharded_env():
+    import torch.multiprocessing as mp
+
+    import finenvs_amd
+
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted((q.get(timeout=240) for _ in range(world)), key=lambda x: x[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # the single-process reference run
+    prices, day_id, _ = _series()
+    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N_TOTAL, redraw="device", seed=77)
+    rew = np.empty((T, N_TOTAL)); done = np.empty((T, N_TOTAL), dtype=np.int32)
+    env.reset()
+    for t in range(T):
+        _, r, d, _ = env.step(_actions(t).to(env.device))
+        rew[t], done[t] = r.cpu().numpy(), d.cpu().numpy()
+    assert done.sum() >= 2 * N_TOTAL  # two episode ends: the eval env redrew its day twice
+    for rank, rews, dones, acts, idx in got:
+        # every rank holds every shard after the gather: (G, T, n) -> (T, N)
+        assert np.array_equal(np.concatenate(list(rews), axis=1), rew)
+        assert np.array_equal(np.concatenate(list(dones), axis=1), done)
+        lo, hi = finenvs_amd.shard_range(N_TOTAL, rank, world)
+        assert np.array_equal(idx, env.env_indices.cpu().numpy()[lo:hi])  # incl. the eval env's redrawn day
+        assert np.array_equal(acts[rank][3], _actions(3)[lo:hi].numpy())
