@@ -29,8 +29,6 @@
 #include <stdlib.h>
 #include <string.h>
 
-#include <cmath>
-#include <limits>
 #include <new>
 
 #include "finenvs_amd.h"

@@ -31,6 +31,10 @@ from ..rng import redraw_day
 from ..spaces import Box
 
 
+# raw hipStream_t of torch's current stream without building a torch.cuda.Stream object (~0.3 us vs ~4 us)
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def shard_range(num_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous block of envs owned by ``rank``."""
     base, rem = divmod(num_envs, world_size)
@@ -92,6 +96,7 @@ class TimeSeriesEnv:
         self.device = set_device(device_id)
         self._lib = _lib.load()
         self._dev = torch.device(self.device)
+        self._dev_index = int(device_id)
         with torch.cuda.device(self._dev):
             self._build_tables(from_files, prices, day_id, tables, num_assets)
             self.set_spaces()
@@ -99,6 +104,8 @@ class TimeSeriesEnv:
 
     # ------------------------------------------------------------------ init path
     def _stream(self) -> int:
+        if _raw_stream is not None:
+            return _raw_stream(self._dev_index)
         return torch.cuda.current_stream(self._dev).cuda_stream
 
     def _build_tables(self, from_files, prices, day_id, tables, num_assets) -> None:
@@ -328,7 +335,7 @@ class TimeSeriesEnv:
             if dones.dtype is not torch.int32 or dones.numel() != N or not dones.is_contiguous() or dones.device != self._dev:
                 raise ValueError("dones_out must be a contiguous int32 tensor of num_envs elements on the env's device")
         rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
-                           torch.cuda.current_stream(self._dev).cuda_stream)
+                           self._stream())
         if rc != 0:
             _lib.check(rc)
         info: Dict = {}

@@ -21,6 +21,8 @@ import torch
 
 from . import _lib
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
 
 class TrajectoryBuffer:
     def __init__(self, num_steps: int, num_envs: int, num_assets: int = 1, device: str = "cuda:0",
@@ -75,6 +77,12 @@ class TrajectoryBuffer:
     def _packed(self) -> torch.Tensor:
         return self._chunks[self._cur]
 
+    def _stream(self) -> int:
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        if _raw_stream is not None:
+            return _raw_stream(idx)
+        return torch.cuda.current_stream(self.device).cuda_stream
+
     def __len__(self) -> int:
         return self.t
 
@@ -90,7 +98,7 @@ class TrajectoryBuffer:
         if self._native:
             if actions.dtype is not torch.float32:
                 actions = actions.float()
-            st = torch.cuda.current_stream(self.device).cuda_stream
+            st = self._stream()
             _lib.check(self._lib.fe_traj_store(
                 self.t, self.N, self.A, actions.contiguous().data_ptr(), rewards.data_ptr(), dones.data_ptr(),
                 self.actions.data_ptr(), self.rewards.data_ptr(), self.dones.data_ptr(), st))
@@ -121,7 +129,7 @@ class TrajectoryBuffer:
         last_values = last_values.reshape(N).float().contiguous()
         ret = torch.empty((T, N), dtype=torch.float32, device=self.device)
         adv = torch.empty((T, N), dtype=torch.float32, device=self.device)
-        st = torch.cuda.current_stream(self.device).cuda_stream
+        st = self._stream()
         _lib.check(self._lib.fe_traj_returns(self.rewards.data_ptr(), self.dones.data_ptr(), values.data_ptr(),
                                              last_values.data_ptr(), T, N, float(gamma), ret.data_ptr(),
                                              adv.data_ptr(), st))
