@@ -36,8 +36,10 @@
 namespace {
 
 constexpr int kBlock = 256;
-// 7 waves per SIMD = 72 VGPRs: the most the step kernel reaches without scratch spills
+// Single-asset kernels: 7 waves per SIMD = 72 VGPRs, the most they reach without scratch spills
 // (8 spills 12-36 B/lane and measured slower); the 20 KiB LDS stage allows 7 workgroups per CU too.
+// Multi-asset kernels carry the per-sleeve LDS arrays (26 KiB at 8 envs x 30 assets -> 6 per CU),
+// so they are built for 6 waves per SIMD (80 VGPRs, no spills).
 #ifndef FE_MIN_WAVES_PER_EU
 #define FE_MIN_WAVES_PER_EU 7
 #endif
@@ -254,30 +256,209 @@ __host__ __device__ inline size_t lds_bytes(int EB, int A) {
     return (b + 15) & ~(size_t)15;
 }
 
+struct TileLds {
+    int64_t *src;  // [EB]  element offset of the observation window's first row in the LR table
+    double *pos;   // [S]   position feature per sleeve
+    double *rew;   // [S]   sleeve reward before the liquidation fee   (A > 1 only)
+    float *shr;    // [S]   long+short after the reward step            (A > 1 only)
+    int *flg;      // [S]   sleeve done flag                            (A > 1 only)
+    int *any;      // [EB]  env-level done                              (A > 1 only)
+};
+
+__device__ __forceinline__ TileLds carve_lds(unsigned char *base, int EB, int S) {
+    TileLds l;
+    l.src = reinterpret_cast<int64_t *>(base);
+    l.pos = reinterpret_cast<double *>(l.src + EB);
+    l.rew = l.pos + S;
+    l.shr = reinterpret_cast<float *>(l.rew + S);
+    l.flg = reinterpret_cast<int *>(l.shr + S);
+    l.any = l.flg + S;
+    return l;
+}
+
+// Phases 1 and 1b for one tile: every thread of the workgroup must call it (it holds barriers).
+// On return l.src / l.pos describe the observation of this step (terminal window on done steps,
+// exactly what step() returns, TSE:321) and the state arrays hold the post-step (post-reset) state.
+template <bool SINGLE>
+__device__ __forceinline__ void account_tile(const Params &p, const TileLds &l, int A, int e, int a, bool active,
+                                             int64_t n, int64_t sl, float action, double *rew_out,
+                                             int32_t *done_out) {
+    const int64_t rs = 4 * (int64_t)A;
+    const int W = p.W;
+    const int64_t L = p.L;
+    Sleeve s;
+    int64_t idx = 0, s0 = 0;
+    bool sdone = false;
+    // ---------------- phase 1: one lane per sleeve ----------------
+    if (active) {
+        idx = p.env_idx[n];
+        s0 = p.spot0[n] + 1;  // TSE:281-282
+        int64_t last = s0 + W - 1;
+        last = last < L ? last : L - 1;  // memory safety only; the done logic keeps last < L
+        const int64_t nxt = last + 1;    // TSE:480
+        const double4 bar = *reinterpret_cast<const double4 *>(p.P + (idx * L + last) * rs + 4 * a);
+        double probe = 0.0;
+        if (nxt < L) probe = p.LR[(idx * L + nxt) * rs + 4 * a];
+        s.cash = p.cash[sl];
+        s.lng = p.lng[sl];
+        s.sht = p.sht[sl];
+        s.margin = p.margin[sl];
+        sleeve_step(p, action, bar.x, bar.y, bar.z, bar.w, s);
+        // termination: bankrupt | end of buffer | next open log-return is NaN, TSE:477-496
+        sdone = s.bankrupt | (nxt >= L) | (probe != probe);
+        l.pos[e * A + a] = s.pos_obs;
+        if constexpr (!SINGLE) {
+            l.rew[e * A + a] = s.rew;
+            l.shr[e * A + a] = s.sht + s.lng;  // num_shares, TSE:288
+            l.flg[e * A + a] = sdone ? 1 : 0;
+        }
+        if (a == 0) {
+            // memory safety only: a well-formed state always has s0 + W <= L
+            const int64_t s0c = s0 + W <= L ? s0 : L - W;
+            l.src[e] = (idx * L + s0c) * rs;
+        }
+    }
+    // ---------------- phase 1b: one lane per env ----------------
+    bool any = sdone;
+    if constexpr (!SINGLE) __syncthreads();
+    if (active && a == 0) {
+        double rew;
+        if constexpr (SINGLE) {
+            float fee = ((any ? 1.0f : 0.0f) * (s.sht + s.lng)) * p.c32;  // TSE:288-289
+            rew = s.rew - (double)fee;
+        } else {
+            any = false;
+            for (int k = 0; k < A; ++k) any |= l.flg[e * A + k] != 0;
+            rew = 0.0;
+            for (int k = 0; k < A; ++k) {  // sleeve contract: sum in asset order
+                float fee = ((any ? 1.0f : 0.0f) * l.shr[e * A + k]) * p.c32;
+                double r = l.rew[e * A + k] - (double)fee;
+                rew = (k == 0) ? r : rew + r;
+            }
+            l.any[e] = any ? 1 : 0;
+        }
+        if (any) {
+            s0 = 0;  // window rewinds to rows 0..W-1, TSE:514-521
+            if (!p.evaluate && p.redraw_mode == 1 && n == p.eval_env) {  // TSE:504-513
+                unsigned long long ctr = p.counters[1];
+                p.env_idx[n] = (int64_t)(((uint64_t)philox_u32(p.seed, ctr) * (uint64_t)p.D) >> 32);
+                p.counters[1] = ctr + 1;
+            }
+        }
+        p.spot0[n] = s0;
+        if (p.evaluate) {  // TSE:523-536
+            const bool term = p.terminated[n] != 0;
+            if (term) rew = 0.0;
+            if (any && !term) {
+                p.terminated[n] = 1;
+                atomicAdd(&p.counters[0], 1ull);
+            }
+            p.ep_ret[n] = (float)((double)p.ep_ret[n] + rew);
+        }
+        rew_out[n] = rew;
+        done_out[n] = any ? 1 : 0;
+        if (p.run_ret) {  // PPO_agent.py:120-132 without its per-step host sync
+            float cr = (float)((double)p.run_ret[n] + rew);
+            if (any) {
+                if (n == p.eval_env) {
+                    p.stat_eval[0] = cr;
+                    p.stat_eval[1] += 1.0f;
+                } else {
+                    atomicAdd(&p.stat_acc[0], 1.0);
+                    atomicAdd(&p.stat_acc[1], (double)cr);
+                    atomicAdd(&p.stat_acc[2], (double)cr * (double)cr);
+                }
+                cr = 0.0f;
+            }
+            p.run_ret[n] = cr;
+        }
+    }
+    if constexpr (!SINGLE) {
+        __syncthreads();
+        if (active) any = l.any[e] != 0;
+    }
+    if (active) {  // state write-back with the episodic reset folded in, TSE:498-502
+        p.cash[sl] = any ? p.S32 : s.cash;
+        p.lng[sl] = any ? 0.0f : s.lng;
+        p.sht[sl] = any ? 0.0f : s.sht;
+        p.margin[sl] = any ? 0.0 : s.margin;
+    }
+}
+
+// reset(): the observation descriptors of the CURRENT state (TSE:423-435); changes no state.
+__device__ __forceinline__ void describe_tile(const Params &p, const TileLds &l, int A, int e, int a, bool active,
+                                              int64_t n, int64_t sl) {
+    if (!active) return;
+    const int64_t rs = 4 * (int64_t)A;
+    const int64_t idx = p.env_idx[n];
+    const int64_t s0 = p.spot0[n];
+    int64_t last = s0 + p.W - 1;
+    last = last < p.L ? last : p.L - 1;
+    const double C = p.P[(idx * p.L + last) * rs + 4 * a + 3];
+    l.pos[e * A + a] = (double)(p.lng[sl] - p.sht[sl]) * C / p.S;
+    if (a == 0) {
+        const int64_t s0c = s0 + p.W <= p.L ? s0 : p.L - p.W;
+        l.src[e] = (idx * p.L + s0c) * rs;
+    }
+}
+
+// Phase 2 for one tile: l.src / l.pos -> (ebt, W, 5A) observation at dst, through this wavefront's
+// private LDS image.  No workgroup barrier inside.
+template <typename OT, int VEC, bool SINGLE>
+__device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, OT *stage, int A, int ebt, OT *dst,
+                                            int lane, int wave) {
+    constexpr int TPI = kStageBytes / (5 * (int)sizeof(OT));  // tuples per wave iteration
+    constexpr int G = TPI / 64;                                // tuples per lane per iteration
+    const uint32_t WA = (uint32_t)p.W * (uint32_t)A;           // 32-byte table tuples per env
+    const uint32_t tuples = (uint32_t)ebt * WA;
+    for (uint32_t base = wave * TPI; base < tuples; base += 4 * TPI) {
+        double4 v[G];
+        double pz[G];
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            const uint32_t t = base + gi * 64 + lane;
+            const uint32_t tc = t < tuples ? t : tuples - 1;  // tail lanes re-read the last tuple
+            const uint32_t ee = fdiv(tc, p.div_WA);           // env within the tile
+            const uint32_t r = tc - ee * WA;                  // (row j, asset a) = r / A, r % A
+            const uint32_t aa = SINGLE ? 0u : r - fdiv(r, p.div_A) * (uint32_t)A;
+            v[gi] = *reinterpret_cast<const double4 *>(p.LR + l.src[ee] + 4u * r);
+            pz[gi] = l.pos[ee * A + aa];
+        }
+#pragma unroll
+        for (int gi = 0; gi < G; ++gi) {
+            OT *w = stage + (gi * 64 + lane) * 5;
+            w[0] = (OT)v[gi].x; w[1] = (OT)v[gi].y; w[2] = (OT)v[gi].z; w[3] = (OT)v[gi].w;
+            w[4] = (OT)pz[gi];
+        }
+        // the image is private to this wavefront: order its LDS writes before the reads below
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t left = tuples - base;
+        const uint32_t nvalid = (left < (uint32_t)TPI ? left : (uint32_t)TPI) * 5u / VEC;  // packs to store
+        const Pack<OT, VEC> *rd = reinterpret_cast<const Pack<OT, VEC> *>(stage);
+        Pack<OT, VEC> *o = reinterpret_cast<Pack<OT, VEC> *>(dst + (size_t)base * 5u);
+        constexpr int kStores = TPI * 5 / VEC / 64;  // 5 full-width store instructions at 16 B/lane
+#pragma unroll
+        for (int i = 0; i < kStores; ++i) {
+            const uint32_t c = (uint32_t)lane + 64u * i;
+            if (c < nvalid) o[c] = rd[c];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();  // reads done before the next iteration overwrites the image
+    }
+}
+
 template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY>
-__global__ __launch_bounds__(kBlock, FE_MIN_WAVES_PER_EU) void fe_env_kernel(const Params p) {
+__global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES_PER_EU - 1) void fe_env_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
-    const int S = EB * A;
-    int64_t *s_src = reinterpret_cast<int64_t *>(smem + 4 * kStageBytes);
-    double *s_pos = reinterpret_cast<double *>(s_src + EB);
-    double *s_rew = s_pos + S;
-    float *s_shr = reinterpret_cast<float *>(s_rew + S);
-    int *s_flg = reinterpret_cast<int *>(s_shr + S);
-    int *s_any = s_flg + S;
-
+    const TileLds l = carve_lds(smem + 4 * kStageBytes, EB, EB * A);
     const int tid = threadIdx.x;
     const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
     const int a = SINGLE ? 0 : tid - e * A;
-    const int64_t rs = 4 * (int64_t)A;  // table row stride, doubles
-    const int W = p.W;
-    const int64_t L = p.L;
-    const uint32_t env_elems = p.env_elems;
-    const uint32_t WA = (uint32_t)W * (uint32_t)A;  // 32-byte table tuples per env
     const int lane = tid & 63, wave = tid >> 6;
-    constexpr int TPI = kStageBytes / (5 * (int)sizeof(OT));  // tuples per wave iteration
-    constexpr int G = TPI / 64;                                // tuples per lane per iteration
     OT *stage = reinterpret_cast<OT *>(smem + wave * kStageBytes);
 
     for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
@@ -286,159 +467,155 @@ __global__ __launch_bounds__(kBlock, FE_MIN_WAVES_PER_EU) void fe_env_kernel(con
         const bool active = e < ebt;
         const int64_t n = n0 + e;
         const int64_t sl = n * A + a;  // sleeve index in the (N, A) state arrays
-
-        // ---------------- phase 1: one lane per sleeve ----------------
-        Sleeve s;
-        int64_t idx = 0, s0 = 0;
-        bool sdone = false;
-        if (active) {
-            idx = p.env_idx[n];
-            if constexpr (RESET_ONLY) {
-                s0 = p.spot0[n];
-                int64_t last = s0 + W - 1;
-                last = last < L ? last : L - 1;
-                const double C = p.P[(idx * L + last) * rs + 4 * a + 3];
-                s_pos[e * A + a] = (double)(p.lng[sl] - p.sht[sl]) * C / p.S;
-            } else {
-                s0 = p.spot0[n] + 1;  // TSE:281-282
-                int64_t last = s0 + W - 1;
-                last = last < L ? last : L - 1;  // memory safety only; the done logic keeps last < L
-                const int64_t nxt = last + 1;    // TSE:480
-                const double4 bar = *reinterpret_cast<const double4 *>(p.P + (idx * L + last) * rs + 4 * a);
-                double probe = 0.0;
-                if (nxt < L) probe = p.LR[(idx * L + nxt) * rs + 4 * a];
-                s.cash = p.cash[sl];
-                s.lng = p.lng[sl];
-                s.sht = p.sht[sl];
-                s.margin = p.margin[sl];
-                sleeve_step(p, p.actions[sl], bar.x, bar.y, bar.z, bar.w, s);
-                // termination: bankrupt | end of buffer | next open log-return is NaN, TSE:477-496
-                sdone = s.bankrupt | (nxt >= L) | (probe != probe);
-                s_pos[e * A + a] = s.pos_obs;
-                if constexpr (!SINGLE) {
-                    s_rew[e * A + a] = s.rew;
-                    s_shr[e * A + a] = s.sht + s.lng;  // num_shares, TSE:288
-                    s_flg[e * A + a] = sdone ? 1 : 0;
-                }
-            }
-            if (a == 0) {
-                // memory safety only: a well-formed state always has s0 + W <= L
-                const int64_t s0c = s0 + W <= L ? s0 : L - W;
-                s_src[e] = (idx * L + s0c) * rs;
-            }
+        if constexpr (RESET_ONLY) {
+            describe_tile(p, l, A, e, a, active, n, sl);
+            __syncthreads();
+        } else {
+            account_tile<SINGLE>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
+            if constexpr (SINGLE) __syncthreads();
         }
-
-        // ---------------- phase 1b: one lane per env ----------------
-        if constexpr (!RESET_ONLY) {
-            bool any = sdone;
-            if constexpr (!SINGLE) __syncthreads();
-            if (active && a == 0) {
-                double rew;
-                if constexpr (SINGLE) {
-                    float fee = ((any ? 1.0f : 0.0f) * (s.sht + s.lng)) * p.c32;  // TSE:288-289
-                    rew = s.rew - (double)fee;
-                } else {
-                    any = false;
-                    for (int k = 0; k < A; ++k) any |= s_flg[e * A + k] != 0;
-                    rew = 0.0;
-                    for (int k = 0; k < A; ++k) {  // sleeve contract: sum in asset order
-                        float fee = ((any ? 1.0f : 0.0f) * s_shr[e * A + k]) * p.c32;
-                        double r = s_rew[e * A + k] - (double)fee;
-                        rew = (k == 0) ? r : rew + r;
-                    }
-                    s_any[e] = any ? 1 : 0;
-                }
-                if (any) {
-                    s0 = 0;  // window rewinds to rows 0..W-1, TSE:514-521
-                    if (!p.evaluate && p.redraw_mode == 1 && n == p.eval_env) {  // TSE:504-513
-                        unsigned long long ctr = p.counters[1];
-                        p.env_idx[n] = (int64_t)(((uint64_t)philox_u32(p.seed, ctr) * (uint64_t)p.D) >> 32);
-                        p.counters[1] = ctr + 1;
-                    }
-                }
-                p.spot0[n] = s0;
-                if (p.evaluate) {  // TSE:523-536
-                    const bool term = p.terminated[n] != 0;
-                    if (term) rew = 0.0;
-                    if (any && !term) {
-                        p.terminated[n] = 1;
-                        atomicAdd(&p.counters[0], 1ull);
-                    }
-                    p.ep_ret[n] = (float)((double)p.ep_ret[n] + rew);
-                }
-                p.rew[n] = rew;
-                p.done[n] = any ? 1 : 0;
-                if (p.run_ret) {  // PPO_agent.py:120-132 without its per-step host sync
-                    float cr = (float)((double)p.run_ret[n] + rew);
-                    if (any) {
-                        if (n == p.eval_env) {
-                            p.stat_eval[0] = cr;
-                            p.stat_eval[1] += 1.0f;
-                        } else {
-                            atomicAdd(&p.stat_acc[0], 1.0);
-                            atomicAdd(&p.stat_acc[1], (double)cr);
-                            atomicAdd(&p.stat_acc[2], (double)cr * (double)cr);
-                        }
-                        cr = 0.0f;
-                    }
-                    p.run_ret[n] = cr;
-                }
-            }
-            if constexpr (!SINGLE) {
-                __syncthreads();
-                if (active) any = s_any[e] != 0;
-            }
-            if (active) {  // state write-back with the episodic reset folded in, TSE:498-502
-                p.cash[sl] = any ? p.S32 : s.cash;
-                p.lng[sl] = any ? 0.0f : s.lng;
-                p.sht[sl] = any ? 0.0f : s.sht;
-                p.margin[sl] = any ? 0.0 : s.margin;
-            }
-        }
-        if constexpr (SINGLE || RESET_ONLY) __syncthreads();
-
-        // ---------------- phase 2: observation stream through a wave-private LDS transpose ----------------
-        {
-            const uint32_t tuples = (uint32_t)ebt * WA;
-            OT *dst = reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)env_elems;
-            for (uint32_t base = wave * TPI; base < tuples; base += 4 * TPI) {
-                double4 v[G];
-                double pz[G];
-#pragma unroll
-                for (int gi = 0; gi < G; ++gi) {
-                    const uint32_t t = base + gi * 64 + lane;
-                    const uint32_t tc = t < tuples ? t : tuples - 1;  // tail lanes re-read the last tuple
-                    const uint32_t ee = fdiv(tc, p.div_WA);           // env within the tile
-                    const uint32_t r = tc - ee * WA;                  // (row j, asset a) = r / A, r % A
-                    const uint32_t aa = SINGLE ? 0u : r - fdiv(r, p.div_A) * (uint32_t)A;
-                    v[gi] = *reinterpret_cast<const double4 *>(p.LR + s_src[ee] + 4u * r);
-                    pz[gi] = s_pos[ee * A + aa];
-                }
-#pragma unroll
-                for (int gi = 0; gi < G; ++gi) {
-                    OT *w = stage + (gi * 64 + lane) * 5;
-                    w[0] = (OT)v[gi].x; w[1] = (OT)v[gi].y; w[2] = (OT)v[gi].z; w[3] = (OT)v[gi].w;
-                    w[4] = (OT)pz[gi];
-                }
-                // the image is private to this wavefront: order its LDS writes before the reads below
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                const uint32_t left = tuples - base;
-                const uint32_t nvalid = (left < (uint32_t)TPI ? left : (uint32_t)TPI) * 5u / VEC;  // packs to store
-                const Pack<OT, VEC> *rd = reinterpret_cast<const Pack<OT, VEC> *>(stage);
-                Pack<OT, VEC> *o = reinterpret_cast<Pack<OT, VEC> *>(dst + (size_t)base * 5u);
-                constexpr int kStores = TPI * 5 / VEC / 64;  // 5 full-width store instructions at 16 B/lane
-#pragma unroll
-                for (int i = 0; i < kStores; ++i) {
-                    const uint32_t c = (uint32_t)lane + 64u * i;
-                    if (c < nvalid) o[c] = rd[c];
-                }
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();  // reads done before the next iteration overwrites the image
-            }
-        }
+        stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems,
+                                     lane, wave);
         __syncthreads();  // LDS is reused by the next tile
+    }
+}
+
+// ---- f2: K env steps per launch with an in-kernel linear policy ----
+// The policy is the "observation projection" of the north star reduced to its simplest useful
+// form: one weight per (window row, feature), shared by all assets,
+//   action[n][a] = clamp(bias + sum_j sum_c obs[n][j][5a+c] * w[j][c], -1, 1)
+// evaluated by one wavefront per (env, asset): lane l accumulates rows j = l, l+64, ... in row
+// order (c = 0..4 inside a row), then a butterfly (xor 32,16,8,4,2,1) of wavefront shuffles sums
+// the 64 partials.  The observation itself is never materialised: the policy reads the window
+// straight from the L2-resident table through the same (src, pos) descriptors phase 2 uses.
+struct RolloutArgs {
+    const double *weights;  // (W, 5) f64
+    double bias;
+    int32_t K;
+    int64_t *obs_src;    // (N)   in/out: descriptor of the current observation
+    double *obs_pos;     // (N*A) in/out
+    float *actions_out;  // (K, N*A) or null
+    double *rew_out;     // (K, N)
+    int32_t *done_out;   // (K, N)
+};
+
+__host__ __device__ inline size_t rollout_lds_bytes(int EB, int A, int W) {
+    size_t S = (size_t)EB * A;
+    size_t b = (size_t)EB * 8 + S * 8 + S * 8 + S * 4 + S * 4 + (size_t)EB * 4;  // TileLds
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)W * 5 * 8;  // weights
+    b += S * 4;              // actions
+    return (b + 15) & ~(size_t)15;
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(kBlock) void fe_rollout_linear_kernel(const Params p, const RolloutArgs r) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const int S = EB * A;
+    const TileLds l = carve_lds(smem, EB, S);
+    size_t off = (size_t)EB * 8 + (size_t)S * 8 + (size_t)S * 8 + (size_t)S * 4 + (size_t)S * 4 + (size_t)EB * 4;
+    off = (off + 7) & ~(size_t)7;
+    double *s_w = reinterpret_cast<double *>(smem + off);
+    float *s_act = reinterpret_cast<float *>(s_w + (size_t)p.W * 5);
+    const int tid = threadIdx.x;
+    const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
+    const int a = SINGLE ? 0 : tid - e * A;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int W = p.W;
+    const int64_t NA = p.N * A;
+    for (int i = tid; i < W * 5; i += kBlock) s_w[i] = r.weights[i];
+
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        const bool active = e < ebt;
+        const int64_t n = n0 + e;
+        const int64_t sl = n * A + a;
+        if (active) {
+            if (a == 0) l.src[e] = r.obs_src[n];
+            l.pos[e * A + a] = r.obs_pos[sl];
+        }
+        __syncthreads();
+        for (int k = 0; k < r.K; ++k) {
+            // policy: one wavefront per (env, asset) pair of the tile
+            for (int q = wave; q < ebt * A; q += kBlock / 64) {
+                const int ee = SINGLE ? q : (int)fdiv((uint32_t)q, p.div_A);
+                const int aa = SINGLE ? 0 : q - ee * A;
+                const double *src = p.LR + l.src[ee];
+                const double pos = l.pos[q];
+                double acc = 0.0;
+                for (int j = lane; j < W; j += 64) {
+                    const double4 v = *reinterpret_cast<const double4 *>(src + ((int64_t)j * A + aa) * 4);
+                    const double *wr = s_w + j * 5;
+                    acc += v.x * wr[0];
+                    acc += v.y * wr[1];
+                    acc += v.z * wr[2];
+                    acc += v.w * wr[3];
+                    acc += pos * wr[4];
+                }
+#pragma unroll
+                for (int m = 32; m >= 1; m >>= 1) acc = acc + __shfl_xor(acc, m, 64);
+                double a64 = r.bias + acc;
+                a64 = a64 < -1.0 ? -1.0 : (a64 > 1.0 ? 1.0 : a64);
+                if (lane == 0) s_act[q] = (float)a64;
+            }
+            __syncthreads();
+            const float act = active ? s_act[e * A + a] : 0.0f;
+            if (active && r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
+            account_tile<SINGLE>(p, l, A, e, a, active, n, sl, act, r.rew_out + (int64_t)k * p.N,
+                                 r.done_out + (int64_t)k * p.N);
+            __syncthreads();  // the new observation's descriptors are complete; state stores are visible
+        }
+        if (active) {
+            if (a == 0) r.obs_src[n] = l.src[e];
+            r.obs_pos[sl] = l.pos[e * A + a];
+        }
+        __syncthreads();
+    }
+}
+
+// descriptors of the current state's observation (reset() semantics), one lane per sleeve
+template <bool SINGLE>
+__global__ __launch_bounds__(kBlock) void fe_describe_kernel(const Params p, int64_t *obs_src, double *obs_pos) {
+    const int A = SINGLE ? 1 : p.A;
+    const int64_t NA = p.N * A;
+    const int64_t rs = 4 * (int64_t)A;
+    for (int64_t sl = blockIdx.x * (int64_t)kBlock + threadIdx.x; sl < NA; sl += (int64_t)gridDim.x * kBlock) {
+        const int64_t n = SINGLE ? sl : sl / A;
+        const int a = SINGLE ? 0 : (int)(sl - n * A);
+        const int64_t idx = p.env_idx[n], s0 = p.spot0[n];
+        int64_t last = s0 + p.W - 1;
+        last = last < p.L ? last : p.L - 1;
+        const double C = p.P[(idx * p.L + last) * rs + 4 * a + 3];
+        obs_pos[sl] = (double)(p.lng[sl] - p.sht[sl]) * C / p.S;
+        if (a == 0) {
+            const int64_t s0c = s0 + p.W <= p.L ? s0 : p.L - p.W;
+            obs_src[n] = (idx * p.L + s0c) * rs;
+        }
+    }
+}
+
+// materialise the observation a pair of descriptor arrays stands for (phase 2 alone)
+template <typename OT, int VEC, bool SINGLE>
+__global__ __launch_bounds__(kBlock) void fe_render_kernel(const Params p, const int64_t *obs_src, const double *obs_pos) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const TileLds l = carve_lds(smem + 4 * kStageBytes, EB, EB * A);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    OT *stage = reinterpret_cast<OT *>(smem + wave * kStageBytes);
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        for (int i = tid; i < ebt; i += kBlock) l.src[i] = obs_src[n0 + i];
+        for (int i = tid; i < ebt * A; i += kBlock) l.pos[i] = obs_pos[n0 * A + i];
+        __syncthreads();
+        stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems,
+                                     lane, wave);
+        __syncthreads();
     }
 }
 
@@ -720,6 +897,72 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
     env->p.rew = rewards;
     env->p.done = dones;
     return launch_env<false>(env, (hipStream_t)stream);
+}
+
+int fe_env_describe(fe_env *env, int64_t *obs_src, double *obs_pos, void *stream) {
+    if (!env || !obs_src || !obs_pos) return fail(FE_ERR_ARG, "fe_env_describe: null argument");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_describe: state not bound");
+    const Params &p = env->p;
+    dim3 g(grid_for(p.N * p.A)), b(kBlock);
+    if (p.A == 1)
+        hipLaunchKernelGGL(fe_describe_kernel<true>, g, b, 0, (hipStream_t)stream, p, obs_src, obs_pos);
+    else
+        hipLaunchKernelGGL(fe_describe_kernel<false>, g, b, 0, (hipStream_t)stream, p, obs_src, obs_pos);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_env_describe launch");
+    return FE_OK;
+}
+
+int fe_env_render(fe_env *env, const int64_t *obs_src, const double *obs_pos, void *obs, void *stream) {
+    if (!env || !obs_src || !obs_pos || !obs) return fail(FE_ERR_ARG, "fe_env_render: null argument");
+    Params p = env->p;
+    p.obs = obs;
+    const bool f32 = env->cfg.obs_is_f32 != 0, single = p.A == 1;
+    dim3 g(env->grid), b(kBlock);
+    hipStream_t st = (hipStream_t)stream;
+    const size_t lds = env->lds;
+#define FE_RENDER(OT, VEC)                                                                                 \
+    do {                                                                                                   \
+        if (single) hipLaunchKernelGGL((fe_render_kernel<OT, VEC, true>), g, b, lds, st, p, obs_src, obs_pos);  \
+        else hipLaunchKernelGGL((fe_render_kernel<OT, VEC, false>), g, b, lds, st, p, obs_src, obs_pos);        \
+    } while (0)
+    if (f32) {
+        if (env->vec == 4) FE_RENDER(float, 4);
+        else if (env->vec == 2) FE_RENDER(float, 2);
+        else FE_RENDER(float, 1);
+    } else {
+        if (env->vec == 2) FE_RENDER(double, 2);
+        else FE_RENDER(double, 1);
+    }
+#undef FE_RENDER
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_env_render launch");
+    return FE_OK;
+}
+
+int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32_t K, int64_t *obs_src,
+                          double *obs_pos, float *actions_out, double *rewards_out, int32_t *dones_out,
+                          void *stream) {
+    if (!env || !weights || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
+        return fail(FE_ERR_ARG, "fe_env_rollout_linear: bad argument");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_linear: state not bound");
+    const Params &p = env->p;
+    const size_t lds = rollout_lds_bytes(p.EB, p.A, p.W);
+    if (lds > 64 * 1024) return fail(FE_ERR_ARG, "fe_env_rollout_linear: window too long for the in-kernel policy (W=%d)", p.W);
+    RolloutArgs r;
+    r.weights = weights; r.bias = bias; r.K = K; r.obs_src = obs_src; r.obs_pos = obs_pos;
+    r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
+    // state lives in HBM between steps but every tile is revisited by the same workgroup, so a
+    // grid of one workgroup per tile (capped) keeps the K-step loop entirely inside the launch
+    int64_t grid = p.num_tiles < 8 * 256 ? p.num_tiles : 8 * 256;
+    dim3 g((unsigned)grid), b(kBlock);
+    if (p.A == 1)
+        hipLaunchKernelGGL(fe_rollout_linear_kernel<true>, g, b, lds, (hipStream_t)stream, p, r);
+    else
+        hipLaunchKernelGGL(fe_rollout_linear_kernel<false>, g, b, lds, (hipStream_t)stream, p, r);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_linear launch");
+    return FE_OK;
 }
 
 int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream) {

@@ -71,3 +71,59 @@ class GraphedRollout:
         if self.traj is not None:
             self.traj.t = self.K
         return self.obs
+
+
+class FusedLinearRollout:
+    """K env steps per launch with an in-kernel linear policy (SURVEY.md 8f.2, C ABI
+    ``fe_env_rollout_linear``): the whole loop
+
+        states = env.reset()
+        for k in range(K): actions = policy(states); states, r, d, _ = env.step(actions)
+
+    (examples/time_series/PPO_LSTM_training_SPY.py:22-28) inside one kernel, for the policy
+    ``clamp(bias + <obs window of the asset, weights (W, 5)>, -1, 1)``.  Observations are never
+    written to HBM during the rollout; ``observation()`` materialises the current one on demand.
+    State, evaluate-mode metrics and EpisodeStats advance exactly as K calls of ``env.step``."""
+
+    def __init__(self, env, weights: torch.Tensor, bias: float = 0.0):
+        W = env.num_intervals
+        if tuple(weights.shape) != (W, 5):
+            raise ValueError(f"weights must be ({W}, 5): one weight per window row and feature")
+        if env.redraw != "device" and not env.evaluate:
+            raise ValueError('the fused rollout needs redraw="device" (or evaluate mode): no host in the loop')
+        self.env = env
+        self.weights = weights.detach().to(device=env._dev, dtype=torch.float64).contiguous()
+        self.bias = float(bias)
+        self.obs_src = torch.empty((env.num_envs,), dtype=torch.int64, device=env._dev)
+        self.obs_pos = torch.empty((env.num_envs, env.num_assets), dtype=torch.float64, device=env._dev)
+        self.sync_from_env()
+
+    def sync_from_env(self) -> None:
+        """Point the descriptors at the observation ``env.reset()`` would render now."""
+        from . import _lib
+
+        _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                                                 self.env._stream()))
+
+    def run(self, num_steps: int, record_actions: bool = True):
+        """Returns (actions (K, N, A) f32 or None, rewards (K, N) f64, dones (K, N) int32)."""
+        from . import _lib
+
+        env, K = self.env, int(num_steps)
+        N, A = env.num_envs, env.num_assets
+        actions = torch.empty((K, N, A), dtype=torch.float32, device=env._dev) if record_actions else None
+        rewards = torch.empty((K, N), dtype=torch.float64, device=env._dev)
+        dones = torch.empty((K, N), dtype=torch.int32, device=env._dev)
+        _lib.check(env._lib.fe_env_rollout_linear(
+            env._handle, self.weights.data_ptr(), self.bias, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+            actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
+        return actions, rewards, dones
+
+    def observation(self) -> torch.Tensor:
+        """The (N, W, 5A) observation the next policy evaluation will see."""
+        from . import _lib
+
+        obs = self.env._next_obs()
+        _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                                               obs.data_ptr(), self.env._stream()))
+        return obs

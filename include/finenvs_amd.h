@@ -116,6 +116,28 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
  */
 int fe_env_bind_stats(fe_env *env, float *running_returns, double *accumulators, float *eval_return);
 
+/*
+ * K env steps in ONE launch with an in-kernel linear policy (fused rollout with a
+ * policy hook).  The policy sees the observation the reference's loop would feed it --
+ * states = env.reset(), then the obs returned by the previous step
+ * (examples/time_series/PPO_LSTM_training_SPY.py:22-28) -- but the observation is never
+ * written to HBM: it is described by obs_src (N) i64 / obs_pos (N*A) f64 (window offset into the
+ * log-return table + position feature), which fe_env_describe initialises from the current
+ * state (reset() semantics), fe_env_rollout_linear advances, and fe_env_render turns into the
+ * (N, W, 5*A) tensor on demand.
+ *   action[n][a] = clamp(bias + sum_j sum_c obs[n][j][5a+c] * weights[j][c], -1, 1), cast to f32;
+ *   the sum runs per 64-lane wavefront: lane l adds rows j = l, l+64, ... in order (c = 0..4),
+ *   then a butterfly over lane xor 32,16,8,4,2,1 -- part of the contract (bit-reproducible).
+ * weights (W, 5) f64; actions_out (K, N*A) f32 may be NULL; rewards_out (K, N) f64;
+ * dones_out (K, N) i32.  State, evaluate-mode metrics and bound statistics advance exactly as K
+ * calls of fe_env_step would.
+ */
+int fe_env_describe(fe_env *env, int64_t *obs_src, double *obs_pos, void *stream);
+int fe_env_render(fe_env *env, const int64_t *obs_src, const double *obs_pos, void *obs, void *stream);
+int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32_t K, int64_t *obs_src,
+                          double *obs_pos, float *actions_out, double *rewards_out, int32_t *dones_out,
+                          void *stream);
+
 /* env_indices[env] = day (the host half of TSE:510-513 when redraw_mode == 0). */
 int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream);
 

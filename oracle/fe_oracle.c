@@ -389,3 +389,38 @@ void fo_discounted_returns(const double *rew, const int32_t *done, const float *
         }
     }
 }
+
+/*
+ * f2: the in-kernel linear policy of fe_env_rollout_linear, restated on a materialised
+ * observation (N, W, 5A) f64.  The summation order is part of the contract: 64 partial sums
+ * (lane l takes rows l, l+64, ... in order, features 0..4 inside a row), then a butterfly over
+ * lane xor 32,16,8,4,2,1; action = (float)clamp(bias + sum, -1, 1); NaN passes through.
+ */
+void fo_policy_linear(const double *obs, const double *weights, double bias, int64_t N, int32_t W,
+                      int32_t A, float *actions_out) {
+    for (int64_t n = 0; n < N; ++n)
+        for (int32_t a = 0; a < A; ++a) {
+            double part[64];
+            for (int l = 0; l < 64; ++l) {
+                double acc = 0.0;
+                for (int32_t j = l; j < W; j += 64) {
+                    const double *row = obs + ((n * W + j) * (int64_t)A + a) * 5;
+                    const double *wr = weights + (int64_t)j * 5;
+                    acc += row[0] * wr[0];
+                    acc += row[1] * wr[1];
+                    acc += row[2] * wr[2];
+                    acc += row[3] * wr[3];
+                    acc += row[4] * wr[4];
+                }
+                part[l] = acc;
+            }
+            for (int m = 32; m >= 1; m >>= 1) {
+                double nxt[64];
+                for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ m];
+                memcpy(part, nxt, sizeof(part));
+            }
+            double a64 = bias + part[0];
+            a64 = a64 < -1.0 ? -1.0 : (a64 > 1.0 ? 1.0 : a64);
+            actions_out[n * A + a] = (float)a64;
+        }
+}

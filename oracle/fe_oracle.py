@@ -101,6 +101,17 @@ def discounted_returns(rew: np.ndarray, done: np.ndarray, last_values: np.ndarra
     return out
 
 
+def policy_linear(obs: np.ndarray, weights: np.ndarray, bias: float) -> np.ndarray:
+    """Actions (N, A) f32 of the in-kernel linear policy on a materialised observation (N, W, 5A)."""
+    obs = np.ascontiguousarray(obs, dtype=np.float64)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    N, W, c5 = obs.shape
+    A = c5 // 5
+    out = np.empty((N, A), dtype=np.float32)
+    lib().fo_policy_linear(_p(obs), _p(weights), C.c_double(bias), C.c_int64(N), C.c_int32(W), C.c_int32(A), _p(out))
+    return out
+
+
 class OracleEnv:
     """numpy-state mirror of TimeSeriesEnv driven by fo_step / fo_reset_obs."""
 
@@ -122,7 +133,9 @@ class OracleEnv:
         seed: int = 0,
         eval_env: Optional[int] = None,
         nthreads: int = 1,
+        auto_emit: bool = True,
     ):
+        self.auto_emit = auto_emit  # False: leave the evaluate-mode metrics alone (fused K-step launches)
         self.P = np.ascontiguousarray(prices, dtype=np.float64)
         self.LR = np.ascontiguousarray(logret, dtype=np.float64)
         D, L, c4 = self.P.shape
@@ -167,7 +180,7 @@ class OracleEnv:
         if rc != 0:
             raise RuntimeError(f"fo_step failed: {rc}")
         info: Dict = {}
-        if self.cfg.evaluate and int(self.n_terminated[0]) == self.N:
+        if self.auto_emit and self.cfg.evaluate and int(self.n_terminated[0]) == self.N:
             info = {"returns": self.episode_returns.copy()}
             self.terminated[:] = 0
             self.episode_returns[:] = 0
