@@ -946,9 +946,18 @@ int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32
     if (!env || !weights || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
         return fail(FE_ERR_ARG, "fe_env_rollout_linear: bad argument");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_linear: state not bound");
-    const Params &p = env->p;
+    Params p = env->p;
+    // the rollout is latency-bound (policy -> accounting -> policy ...): 64 sleeves per workgroup measured
+    // best at 64k envs (tools/fused_bench.py), independent of the tile the streaming step kernel uses
+    int64_t cap = kBlock / p.A > 0 ? kBlock / p.A : 1;
+    int64_t eb = 64 / p.A;
+    if (eb < 8) eb = 8;  // but never fewer than 8 envs per workgroup when they fit
+    if (eb > cap) eb = cap;
+    const char *ov = getenv("FE_TILE_ENVS");
+    if (ov && atoi(ov) > 0) eb = atoi(ov) < cap ? atoi(ov) : cap;
+    p.EB = (int)eb;
+    p.num_tiles = (p.N + eb - 1) / eb;
     const size_t lds = rollout_lds_bytes(p.EB, p.A, p.W);
-    if (lds > 64 * 1024) return fail(FE_ERR_ARG, "fe_env_rollout_linear: window too long for the in-kernel policy (W=%d)", p.W);
     RolloutArgs r;
     r.weights = weights; r.bias = bias; r.K = K; r.obs_src = obs_src; r.obs_pos = obs_pos;
     r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
