@@ -65,20 +65,32 @@ def cpu_baseline(A: int, W: int, budget_s: float = 12.0):
     # the GPU box gives one GPU a 16-core share of the host (os.cpu_count() reports the whole machine)
     cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("FE_CPU_THREADS", "16")))
     n = 65536 if A == 1 else 4096
-    env = fo.OracleEnv(P, LR, W, num_envs=n, redraw_mode=1, seed=1, nthreads=cores)
     g = torch.Generator().manual_seed(7)
     acts = [(torch.rand((n, A), generator=g) * 2 - 1).float().numpy() for _ in range(8)]
-    env.step(acts[0])
-    t0 = time.perf_counter()
-    k = 0
-    while True:
-        env.step(acts[k % 8])
-        k += 1
-        el = time.perf_counter() - t0
-        if el > budget_s:
-            break
-    return {"value": n * k / el, "unit": "env-steps/s", "cores": cores, "kind": "port",
+
+    def timed(threads, budget):
+        env = fo.OracleEnv(P, LR, W, num_envs=n, redraw_mode=1, seed=1, nthreads=threads)
+        env.step(acts[0])
+        t0 = time.perf_counter()
+        k = 0
+        while True:
+            env.step(acts[k % 8])
+            k += 1
+            el = time.perf_counter() - t0
+            if el > budget:
+                return n * k / el, k, el
+
+    rate, k, el = timed(cores, budget_s)
+    rate1, _, _ = timed(1, 3.0)
+    model = "unknown"
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
+    except Exception:  # noqa: BLE001
+        pass
+    return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
             "sample": f"{k} steps of {n} envs x {A} assets x W{W} (oracle/fe_oracle.c, OpenMP {cores} threads, {el:.1f} s)",
+            "value_1thread": rate1, "cpu_model": model, "host_cpus_visible": os.cpu_count(),
             "reference_quoted": REFERENCE_CPU_QUOTED}
 
 
