@@ -276,36 +276,68 @@ __device__ __forceinline__ TileLds carve_lds(unsigned char *base, int EB, int S)
     return l;
 }
 
-// Phases 1 and 1b for one tile: every thread of the workgroup must call it (it holds barriers).
-// On return l.src / l.pos describe the observation of this step (terminal window on done steps,
-// exactly what step() returns, TSE:321) and the state arrays hold the post-step (post-reset) state.
+// What phase 1 reads for one sleeve.  Loading is split in two dependent stages so that the step
+// kernel can prefetch them for the NEXT tile while the current tile's observation streams out:
+//   head: env_idx, spot0 (coalesced)          body: state + the bar/probe gathers that need the head
+struct SleeveIn {
+    int64_t idx, s0, nxt;
+    double4 bar;
+    double probe, margin;
+    float cash, lng, sht;
+};
+
+__device__ __forceinline__ void load_head(const Params &p, bool active, int64_t n, int64_t &idx, int64_t &spot) {
+    idx = 0;
+    spot = 0;
+    if (active) {
+        idx = p.env_idx[n];
+        spot = p.spot0[n];
+    }
+}
+
+__device__ __forceinline__ void load_body(const Params &p, int A, int a, bool active, int64_t sl, int64_t idx,
+                                          int64_t spot, SleeveIn &in) {
+    if (!active) return;
+    const int64_t rs = 4 * (int64_t)A;
+    const int64_t L = p.L;
+    in.idx = idx;
+    in.s0 = spot + 1;  // TSE:281-282
+    int64_t last = in.s0 + p.W - 1;
+    last = last < L ? last : L - 1;  // memory safety only; the done logic keeps last < L
+    in.nxt = last + 1;               // TSE:480
+    in.bar = *reinterpret_cast<const double4 *>(p.P + (idx * L + last) * rs + 4 * a);
+    in.probe = 0.0;
+    if (in.nxt < L) in.probe = p.LR[(idx * L + in.nxt) * rs + 4 * a];
+    in.cash = p.cash[sl];
+    in.lng = p.lng[sl];
+    in.sht = p.sht[sl];
+    in.margin = p.margin[sl];
+}
+
+// Phases 1 and 1b for one tile from preloaded inputs: every thread of the workgroup must call it
+// (it holds barriers).  On return l.src / l.pos describe the observation of this step (terminal
+// window on done steps, exactly what step() returns, TSE:321) and the state arrays hold the
+// post-step (post-reset) state.
 template <bool SINGLE>
-__device__ __forceinline__ void account_tile(const Params &p, const TileLds &l, int A, int e, int a, bool active,
-                                             int64_t n, int64_t sl, float action, double *rew_out,
-                                             int32_t *done_out) {
+__device__ __forceinline__ void account_core(const Params &p, const TileLds &l, int A, int e, int a, bool active,
+                                             int64_t n, int64_t sl, const SleeveIn &in, float action,
+                                             double *rew_out, int32_t *done_out) {
     const int64_t rs = 4 * (int64_t)A;
     const int W = p.W;
     const int64_t L = p.L;
     Sleeve s;
-    int64_t idx = 0, s0 = 0;
+    int64_t s0 = 0;
     bool sdone = false;
     // ---------------- phase 1: one lane per sleeve ----------------
     if (active) {
-        idx = p.env_idx[n];
-        s0 = p.spot0[n] + 1;  // TSE:281-282
-        int64_t last = s0 + W - 1;
-        last = last < L ? last : L - 1;  // memory safety only; the done logic keeps last < L
-        const int64_t nxt = last + 1;    // TSE:480
-        const double4 bar = *reinterpret_cast<const double4 *>(p.P + (idx * L + last) * rs + 4 * a);
-        double probe = 0.0;
-        if (nxt < L) probe = p.LR[(idx * L + nxt) * rs + 4 * a];
-        s.cash = p.cash[sl];
-        s.lng = p.lng[sl];
-        s.sht = p.sht[sl];
-        s.margin = p.margin[sl];
-        sleeve_step(p, action, bar.x, bar.y, bar.z, bar.w, s);
+        s0 = in.s0;
+        s.cash = in.cash;
+        s.lng = in.lng;
+        s.sht = in.sht;
+        s.margin = in.margin;
+        sleeve_step(p, action, in.bar.x, in.bar.y, in.bar.z, in.bar.w, s);
         // termination: bankrupt | end of buffer | next open log-return is NaN, TSE:477-496
-        sdone = s.bankrupt | (nxt >= L) | (probe != probe);
+        sdone = s.bankrupt | (in.nxt >= L) | (in.probe != in.probe);
         l.pos[e * A + a] = s.pos_obs;
         if constexpr (!SINGLE) {
             l.rew[e * A + a] = s.rew;
@@ -315,7 +347,7 @@ __device__ __forceinline__ void account_tile(const Params &p, const TileLds &l, 
         if (a == 0) {
             // memory safety only: a well-formed state always has s0 + W <= L
             const int64_t s0c = s0 + W <= L ? s0 : L - W;
-            l.src[e] = (idx * L + s0c) * rs;
+            l.src[e] = (in.idx * L + s0c) * rs;
         }
     }
     // ---------------- phase 1b: one lane per env ----------------
@@ -383,6 +415,18 @@ __device__ __forceinline__ void account_tile(const Params &p, const TileLds &l, 
         p.sht[sl] = any ? 0.0f : s.sht;
         p.margin[sl] = any ? 0.0 : s.margin;
     }
+}
+
+// unpipelined form: load, then account (the fused rollout kernel revisits the same tile every step)
+template <bool SINGLE>
+__device__ __forceinline__ void account_tile(const Params &p, const TileLds &l, int A, int e, int a, bool active,
+                                             int64_t n, int64_t sl, float action, double *rew_out,
+                                             int32_t *done_out) {
+    int64_t idx, spot;
+    SleeveIn in;
+    load_head(p, active, n, idx, spot);
+    load_body(p, A, a, active, sl, idx, spot, in);
+    account_core<SINGLE>(p, l, A, e, a, active, n, sl, in, action, rew_out, done_out);
 }
 
 // reset(): the observation descriptors of the CURRENT state (TSE:423-435); changes no state.
@@ -461,22 +505,58 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
     const int lane = tid & 63, wave = tid >> 6;
     OT *stage = reinterpret_cast<OT *>(smem + wave * kStageBytes);
 
-    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
-        const int64_t n0 = tile * EB;
-        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
-        const bool active = e < ebt;
-        const int64_t n = n0 + e;
-        const int64_t sl = n * A + a;  // sleeve index in the (N, A) state arrays
-        if constexpr (RESET_ONLY) {
-            describe_tile(p, l, A, e, a, active, n, sl);
+    if constexpr (RESET_ONLY) {
+        for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+            const int64_t n0 = tile * EB;
+            const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+            const int64_t n = n0 + e;
+            describe_tile(p, l, A, e, a, e < ebt, n, n * A + a);
             __syncthreads();
-        } else {
-            account_tile<SINGLE>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
-            if constexpr (SINGLE) __syncthreads();
+            stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
+                                         reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
+            __syncthreads();  // LDS is reused by the next tile
         }
-        stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems,
-                                     lane, wave);
-        __syncthreads();  // LDS is reused by the next tile
+    } else {
+        // Software pipeline over this workgroup's tiles: while tile i streams its observation
+        // (phase 2, the long part), the state + bar gathers of tile i+1 and the index loads of tile
+        // i+2 are already in flight, so only the very first tile pays phase 1's two dependent
+        // memory round trips.
+        const int64_t G = gridDim.x;
+        int64_t tile = blockIdx.x;
+        auto env_of = [&](int64_t t, bool &act) {
+            const int64_t n0 = t * EB;
+            const int64_t left = p.N - n0;
+            act = t < p.num_tiles && (int64_t)e < (left < (int64_t)EB ? left : (int64_t)EB);
+            return n0 + e;
+        };
+        bool act0, act1, act2;
+        int64_t n_cur = env_of(tile, act0), n_nxt = env_of(tile + G, act1), n_nn;
+        int64_t idx1, spot1, idx2, spot2;
+        SleeveIn in_cur, in_nxt;
+        float action_cur = 0.0f, action_nxt = 0.0f;
+        load_head(p, act0, n_cur, idx1, spot1);
+        load_body(p, A, a, act0, n_cur * A + a, idx1, spot1, in_cur);
+        if (act0) action_cur = p.actions[n_cur * A + a];
+        load_head(p, act1, n_nxt, idx1, spot1);
+        for (; tile < p.num_tiles; tile += G) {
+            const int64_t n0 = tile * EB;
+            const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+            account_core<SINGLE>(p, l, A, e, a, act0, n_cur, n_cur * A + a, in_cur, action_cur, p.rew, p.done);
+            if constexpr (SINGLE) __syncthreads();
+            // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
+            load_body(p, A, a, act1, n_nxt * A + a, idx1, spot1, in_nxt);
+            if (act1) action_nxt = p.actions[n_nxt * A + a];
+            n_nn = env_of(tile + 2 * G, act2);
+            load_head(p, act2, n_nn, idx2, spot2);
+            stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
+                                         reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
+            __syncthreads();  // LDS is reused by the next tile
+            in_cur = in_nxt;
+            action_cur = action_nxt;
+            n_cur = n_nxt; act0 = act1;
+            n_nxt = n_nn; act1 = act2;
+            idx1 = idx2; spot1 = spot2;
+        }
     }
 }
 

@@ -28,8 +28,9 @@ def run(eb, grid, steps):
     print(f"EB={info['tile_envs']:4d} grid={info['grid']:5d} lds={info['lds_bytes']:6d}  mean={iv.mean()*1e3:9.2f} us  med={np.median(iv)*1e3:9.2f}  min={iv.min()*1e3:9.2f}  obs-write={obs_bytes/np.median(iv)/1e9:6.2f} TB/s", flush=True)
     del env
 steps = 200 if cfg <= 2 else 20
-ebs = [None, 4, 8, 11, 16, 22, 32, 44, 64, 128] if A == 1 else [None, 1, 2, 4, 8]
+ebs = [int(x) for x in os.environ['SWEEP_EBS'].split(',')] if os.environ.get('SWEEP_EBS') else ([None, 4, 8, 11, 16, 22, 32, 44, 64, 128] if A == 1 else [None, 1, 2, 4, 8])
 for eb in ebs:
     run(eb, None, steps)
-for grid in (512, 768, 1024, 1280, 1536, 2048):
-    run(16 if A == 1 else 8, grid, steps)
+if not os.environ.get('SWEEP_EBS'):
+    for grid in (512, 768, 1024, 1280, 1536, 2048):
+        run(16 if A == 1 else 8, grid, steps)
