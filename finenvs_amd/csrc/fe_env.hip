@@ -516,6 +516,19 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
                                          reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
             __syncthreads();  // LDS is reused by the next tile
         }
+    } else if constexpr (!SINGLE) {
+        // multi-asset tiles stream hundreds of KiB each: phase 1 is <1 % of a tile, no pipelining needed
+        for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+            const int64_t n0 = tile * EB;
+            const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+            const bool active = e < ebt;
+            const int64_t n = n0 + e;
+            const int64_t sl = n * A + a;
+            account_tile<SINGLE>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
+            stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
+                                         reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
+            __syncthreads();  // LDS is reused by the next tile
+        }
     } else {
         // Software pipeline over this workgroup's tiles: while tile i streams its observation
         // (phase 2, the long part), the state + bar gathers of tile i+1 and the index loads of tile
