@@ -1,0 +1,48 @@
+#!/bin/bash
+# CPU-only sanitizer pass (ASan + UBSan) over the host-side native code: the C oracle and the CSV reader.
+# GPU sanitizers are not available on this pool; the HIP kernels are covered by the parity suite instead.
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+OUT=${TMPDIR:-/tmp}/fe_sanitize
+mkdir -p $OUT
+gcc -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -fopenmp -fPIC -shared \
+    -o $OUT/libfe_oracle.so $ROOT/oracle/fe_oracle.c -lm
+cat > $OUT/csv_main.cpp <<'CPP'
+#include <cstdio>
+#include <cstdarg>
+#include <vector>
+#include "finenvs_amd.h"
+extern "C" int fe_set_error(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vfprintf(stderr, fmt, ap); va_end(ap); fputc('\n', stderr); return code; }
+int main(int argc, char **argv) {
+    for (int i = 1; i < argc; ++i) {
+        int64_t cap = fe_csv_count_lines(argv[i]);
+        if (cap < 0) { printf("%s: count error %lld\n", argv[i], (long long)cap); continue; }
+        std::vector<double> p((size_t)(cap > 0 ? cap : 1) * 4); std::vector<int64_t> d(cap + 1), k(cap + 1), s(cap + 1);
+        int64_t rows = fe_csv_read(argv[i], cap, 1, p.data(), d.data(), k.data(), s.data());
+        printf("%s: %lld lines -> %lld rows\n", argv[i], (long long)cap, (long long)rows);
+    }
+    return 0;
+}
+CPP
+g++ -g -O1 -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I $ROOT/include \
+    $OUT/csv_main.cpp $ROOT/finenvs_amd/csrc/fe_csv.cpp -o $OUT/csv_asan
+# inputs: well-formed, ragged, truncated, garbage
+python3 - "$OUT" <<'PY'
+import os, sys
+out = sys.argv[1]
+sys.path.insert(0, os.path.join(os.path.dirname(out), ""))
+rows = ["2020-01-02,09:30:00,1.5,2,1,1.75,10", "2020-01-02,09:31,1.5,2,1,1.75", "01/03/2020,15:59,3,3,3,3,1"]
+open(f"{out}/ok.csv", "w").write("\n".join(rows) + "\n")
+open(f"{out}/nonl.csv", "w").write("\n".join(rows))
+open(f"{out}/trunc.csv", "w").write("2020-01-02,09:30:00,1.5,2")
+open(f"{out}/garbage.csv", "wb").write(bytes(range(256)) * 40)
+open(f"{out}/empty.csv", "w").close()
+open(f"{out}/commas.csv", "w").write(",,,,,,\n,,\n")
+open(f"{out}/long.csv", "w").write("2020-01-02,10:00," + "9" * 400 + ",1,1,1,1\n")
+PY
+$OUT/csv_asan $OUT/ok.csv $OUT/nonl.csv $OUT/trunc.csv $OUT/garbage.csv $OUT/empty.csv $OUT/commas.csv $OUT/long.csv $OUT/missing.csv 2>&1 | grep -v "^fe_csv" || true
+# the oracle under ASan/UBSan: replay the golden suite against the instrumented library
+cd $ROOT
+ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) FE_ORACLE_LIB=$OUT/libfe_oracle.so \
+    python3 -m pytest tests/test_oracle_golden.py -q -x -p no:cacheprovider 2>&1 | tail -3
+echo "sanitizer pass done"
