@@ -34,8 +34,9 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         cmd = [HIPCC] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", LIB]
-        if os.environ.get("FE_MIN_WAVES_PER_EU"):  # tuning experiments only
-            cmd.insert(1, "-DFE_MIN_WAVES_PER_EU=" + os.environ["FE_MIN_WAVES_PER_EU"])
+        for knob in ("FE_MIN_WAVES_PER_EU", "FE_STORE_AUX"):  # tuning experiments only
+            if os.environ.get(knob):
+                cmd.insert(1, f"-D{knob}=" + os.environ[knob])
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)

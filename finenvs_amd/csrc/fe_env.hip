@@ -43,6 +43,15 @@ constexpr int kBlock = 256;
 #ifndef FE_MIN_WAVES_PER_EU
 #define FE_MIN_WAVES_PER_EU 7
 #endif
+// Cache policy of the observation stores.  -2 (default) = chosen per kernel variant: plain global
+// stores for single-asset envs, non-temporal buffer stores (aux 2) for multi-asset envs, whose
+// log-return tables (tens of MB) must survive in the 4 MiB L2 next to a 20-150 GB store stream:
+// measured at 1M envs x 30 assets (tools/store_policy_box.sh) FETCH_SIZE 6.9 GiB -> 0.4 GiB per
+// launch and 26.4 -> 25.0 ms; sc1 (16) gives the same fetch reduction but 25.6 ms; no effect at 1 asset.
+// -1 = plain everywhere; >= 0 = buffer stores with that aux everywhere (experiments).
+#ifndef FE_STORE_AUX
+#define FE_STORE_AUX -2
+#endif
 
 thread_local char g_err[512] = "";
 
@@ -483,10 +492,29 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
         const Pack<OT, VEC> *rd = reinterpret_cast<const Pack<OT, VEC> *>(stage);
         Pack<OT, VEC> *o = reinterpret_cast<Pack<OT, VEC> *>(dst + (size_t)base * 5u);
         constexpr int kStores = TPI * 5 / VEC / 64;  // 5 full-width store instructions at 16 B/lane
+        constexpr int kAux = FE_STORE_AUX == -2 ? (SINGLE ? -1 : 2) : FE_STORE_AUX;
+        if constexpr (kAux >= 0 && sizeof(OT) * VEC == 16) {
+            // observation stores with explicit cache bits (aux: 1 = sc0, 2 = nt, 16 = sc1) through a
+            // buffer descriptor over this wavefront's 5-KiB slab; the descriptor is wave-uniform
+            using u4 = __attribute__((ext_vector_type(4))) unsigned int;
+            const uint64_t basep = reinterpret_cast<uint64_t>(o);
+            const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)basep);
+            const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(basep >> 32));
+            const unsigned nb = __builtin_amdgcn_readfirstlane(nvalid * 16u);
+            auto rsrc = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, nb,
+                                                          0x00020000);
+            const u4 *rd4 = reinterpret_cast<const u4 *>(stage);
 #pragma unroll
-        for (int i = 0; i < kStores; ++i) {
-            const uint32_t c = (uint32_t)lane + 64u * i;
-            if (c < nvalid) o[c] = rd[c];
+            for (int i = 0; i < kStores; ++i) {
+                const uint32_t c = (uint32_t)lane + 64u * i;
+                if (c < nvalid) __builtin_amdgcn_raw_buffer_store_b128(rd4[c], rsrc, c * 16u, 0, kAux);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < kStores; ++i) {
+                const uint32_t c = (uint32_t)lane + 64u * i;
+                if (c < nvalid) o[c] = rd[c];
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();  // reads done before the next iteration overwrites the image
