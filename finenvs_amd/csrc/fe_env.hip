@@ -842,9 +842,16 @@ static const void *kernel_for(bool f32, int vec, bool single) {
 #undef FE_PICK
 }
 
+// Per-call pointers go into a local copy of the parameter block: the env object itself is not
+// modified by reset/step, so concurrent calls on different streams do not race on the host side.
 template <bool RESET_ONLY>
-static int launch_env(fe_env *env, hipStream_t st) {
+static int launch_env(const fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                      hipStream_t st) {
     Params p = env->p;
+    p.actions = actions;
+    p.obs = obs;
+    p.rew = rewards;
+    p.done = dones;
     void *args[] = {&p};
     hipError_t he = hipLaunchKernel(kernel_for<RESET_ONLY>(env->cfg.obs_is_f32 != 0, env->vec, p.A == 1),
                                     dim3(env->grid), dim3(kBlock), args, env->lds, st);
@@ -1006,18 +1013,13 @@ int fe_env_bind_stats(fe_env *env, float *running_returns, double *accumulators,
 int fe_env_reset_obs(fe_env *env, void *obs, void *stream) {
     if (!env || !obs) return fail(FE_ERR_ARG, "fe_env_reset_obs: null argument");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_reset_obs: state not bound");
-    env->p.obs = obs;
-    return launch_env<true>(env, (hipStream_t)stream);
+    return launch_env<true>(env, nullptr, obs, nullptr, nullptr, (hipStream_t)stream);
 }
 
 int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones, void *stream) {
     if (!env || !actions || !obs || !rewards || !dones) return fail(FE_ERR_ARG, "fe_env_step: null argument");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step: state not bound");
-    env->p.actions = actions;
-    env->p.obs = obs;
-    env->p.rew = rewards;
-    env->p.done = dones;
-    return launch_env<false>(env, (hipStream_t)stream);
+    return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream);
 }
 
 int fe_env_describe(fe_env *env, int64_t *obs_src, double *obs_pos, void *stream) {
