@@ -601,6 +601,131 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
     }
 }
 
+// Workgroup barrier that orders LDS traffic only: the fused rollout keeps all cross-lane traffic in
+// LDS, so it must not wait for its (fire-and-forget) global stores the way __syncthreads() does.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+
+// Register-resident account state of one sleeve across the K steps of a fused rollout.
+struct SleeveReg {
+    int64_t idx, spot;  // env_indices[n], env_spots[n][0]
+    float cash, lng, sht;
+    double margin;
+};
+
+// One step of phases 1/1b with the state in registers (the fused rollout): same arithmetic and the
+// same global side effects as account_core (rewards, dones, evaluate-mode metrics, statistics,
+// redraw counter), but cash/shares/margin/spot/idx are only updated in `st`; cross-lane traffic
+// (env-level done, redrawn day) goes through LDS.
+template <bool SINGLE>
+__device__ __forceinline__ void account_keep(const Params &p, const TileLds &l, int64_t *l_idx, int A, int e, int a,
+                                             bool active, int64_t n, SleeveReg &st, float action, double *rew_out,
+                                             int32_t *done_out) {
+    const int64_t rs = 4 * (int64_t)A;
+    const int W = p.W;
+    const int64_t L = p.L;
+    Sleeve s;
+    int64_t s0 = 0;
+    bool sdone = false;
+    if (active) {
+        s0 = st.spot + 1;  // TSE:281-282
+        int64_t last = s0 + W - 1;
+        last = last < L ? last : L - 1;
+        const int64_t nxt = last + 1;
+        const double4 bar = *reinterpret_cast<const double4 *>(p.P + (st.idx * L + last) * rs + 4 * a);
+        double probe = 0.0;
+        if (nxt < L) probe = p.LR[(st.idx * L + nxt) * rs + 4 * a];
+        s.cash = st.cash;
+        s.lng = st.lng;
+        s.sht = st.sht;
+        s.margin = st.margin;
+        sleeve_step(p, action, bar.x, bar.y, bar.z, bar.w, s);
+        sdone = s.bankrupt | (nxt >= L) | (probe != probe);
+        l.pos[e * A + a] = s.pos_obs;
+        if constexpr (!SINGLE) {
+            l.rew[e * A + a] = s.rew;
+            l.shr[e * A + a] = s.sht + s.lng;
+            l.flg[e * A + a] = sdone ? 1 : 0;
+        }
+        if (a == 0) {
+            const int64_t s0c = s0 + W <= L ? s0 : L - W;
+            l.src[e] = (st.idx * L + s0c) * rs;
+        }
+    }
+    bool any = sdone;
+    int64_t new_idx = st.idx;
+    if constexpr (!SINGLE) lds_barrier();
+    if (active && a == 0) {
+        double rew;
+        if constexpr (SINGLE) {
+            float fee = ((any ? 1.0f : 0.0f) * (s.sht + s.lng)) * p.c32;
+            rew = s.rew - (double)fee;
+        } else {
+            any = false;
+            for (int k = 0; k < A; ++k) any |= l.flg[e * A + k] != 0;
+            rew = 0.0;
+            for (int k = 0; k < A; ++k) {
+                float fee = ((any ? 1.0f : 0.0f) * l.shr[e * A + k]) * p.c32;
+                double r = l.rew[e * A + k] - (double)fee;
+                rew = (k == 0) ? r : rew + r;
+            }
+        }
+        if (any && !p.evaluate && p.redraw_mode == 1 && n == p.eval_env) {  // TSE:504-513
+            unsigned long long ctr = p.counters[1];
+            new_idx = (int64_t)(((uint64_t)philox_u32(p.seed, ctr) * (uint64_t)p.D) >> 32);
+            p.counters[1] = ctr + 1;
+        }
+        if constexpr (!SINGLE) {
+            l.any[e] = any ? 1 : 0;
+            l_idx[e] = new_idx;
+        }
+        if (p.evaluate) {  // TSE:523-536
+            const bool term = p.terminated[n] != 0;
+            if (term) rew = 0.0;
+            if (any && !term) {
+                p.terminated[n] = 1;
+                atomicAdd(&p.counters[0], 1ull);
+            }
+            p.ep_ret[n] = (float)((double)p.ep_ret[n] + rew);
+        }
+        rew_out[n] = rew;
+        done_out[n] = any ? 1 : 0;
+        if (p.run_ret) {
+            float cr = (float)((double)p.run_ret[n] + rew);
+            if (any) {
+                if (n == p.eval_env) {
+                    p.stat_eval[0] = cr;
+                    p.stat_eval[1] += 1.0f;
+                } else {
+                    atomicAdd(&p.stat_acc[0], 1.0);
+                    atomicAdd(&p.stat_acc[1], (double)cr);
+                    atomicAdd(&p.stat_acc[2], (double)cr * (double)cr);
+                }
+                cr = 0.0f;
+            }
+            p.run_ret[n] = cr;
+        }
+    }
+    if constexpr (!SINGLE) {
+        lds_barrier();
+        if (active) {
+            any = l.any[e] != 0;
+            new_idx = l_idx[e];
+        }
+    }
+    if (active) {  // episodic reset folded in, TSE:498-521
+        st.cash = any ? p.S32 : s.cash;
+        st.lng = any ? 0.0f : s.lng;
+        st.sht = any ? 0.0f : s.sht;
+        st.margin = any ? 0.0 : s.margin;
+        st.spot = any ? 0 : s0;
+        st.idx = new_idx;
+    }
+}
+
 // ---- f2: K env steps per launch with an in-kernel linear policy ----
 // The policy is the "observation projection" of the north star reduced to its simplest useful
 // form: one weight per (window row, feature), shared by all assets,
@@ -626,11 +751,16 @@ __host__ __device__ inline size_t rollout_lds_bytes(int EB, int A, int W) {
     b = (b + 7) & ~(size_t)7;
     b += (size_t)W * 5 * 8;  // weights
     b += S * 4;              // actions
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)EB * 8;     // redrawn day per env (A > 1)
     return (b + 15) & ~(size_t)15;
 }
 
+#ifndef FE_ROLLOUT_WAVES
+#define FE_ROLLOUT_WAVES 1
+#endif
 template <bool SINGLE>
-__global__ __launch_bounds__(kBlock) void fe_rollout_linear_kernel(const Params p, const RolloutArgs r) {
+__global__ __launch_bounds__(kBlock, FE_ROLLOUT_WAVES) void fe_rollout_linear_kernel(const Params p, const RolloutArgs r) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
@@ -640,6 +770,8 @@ __global__ __launch_bounds__(kBlock) void fe_rollout_linear_kernel(const Params 
     off = (off + 7) & ~(size_t)7;
     double *s_w = reinterpret_cast<double *>(smem + off);
     float *s_act = reinterpret_cast<float *>(s_w + (size_t)p.W * 5);
+    int64_t *l_idx = reinterpret_cast<int64_t *>(
+        smem + ((off + (size_t)p.W * 40 + (size_t)S * 4 + 7) & ~(size_t)7));
     const int tid = threadIdx.x;
     const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
     const int a = SINGLE ? 0 : tid - e * A;
@@ -654,14 +786,24 @@ __global__ __launch_bounds__(kBlock) void fe_rollout_linear_kernel(const Params 
         const bool active = e < ebt;
         const int64_t n = n0 + e;
         const int64_t sl = n * A + a;
+        // the tile's account state moves into registers for the whole K-step loop
+        SleeveReg st;
+        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
         if (active) {
+            st.idx = p.env_idx[n];
+            st.spot = p.spot0[n];
+            st.cash = p.cash[sl];
+            st.lng = p.lng[sl];
+            st.sht = p.sht[sl];
+            st.margin = p.margin[sl];
             if (a == 0) l.src[e] = r.obs_src[n];
             l.pos[e * A + a] = r.obs_pos[sl];
         }
         __syncthreads();
+        const int pairs = ebt * A;
         for (int k = 0; k < r.K; ++k) {
             // policy: one wavefront per (env, asset) pair of the tile
-            for (int q = wave; q < ebt * A; q += kBlock / 64) {
+            for (int q = wave; q < pairs; q += kBlock / 64) {
                 const int ee = SINGLE ? q : (int)fdiv((uint32_t)q, p.div_A);
                 const int aa = SINGLE ? 0 : q - ee * A;
                 const double *src = p.LR + l.src[ee];
@@ -682,16 +824,24 @@ __global__ __launch_bounds__(kBlock) void fe_rollout_linear_kernel(const Params 
                 a64 = a64 < -1.0 ? -1.0 : (a64 > 1.0 ? 1.0 : a64);
                 if (lane == 0) s_act[q] = (float)a64;
             }
-            __syncthreads();
+            lds_barrier();
             const float act = active ? s_act[e * A + a] : 0.0f;
             if (active && r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
-            account_tile<SINGLE>(p, l, A, e, a, active, n, sl, act, r.rew_out + (int64_t)k * p.N,
+            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
                                  r.done_out + (int64_t)k * p.N);
-            __syncthreads();  // the new observation's descriptors are complete; state stores are visible
+            lds_barrier();  // the new observation's descriptors are complete
         }
-        if (active) {
-            if (a == 0) r.obs_src[n] = l.src[e];
+        if (active) {  // state and descriptors go back to HBM once per launch
+            p.cash[sl] = st.cash;
+            p.lng[sl] = st.lng;
+            p.sht[sl] = st.sht;
+            p.margin[sl] = st.margin;
             r.obs_pos[sl] = l.pos[e * A + a];
+            if (a == 0) {
+                p.env_idx[n] = st.idx;
+                p.spot0[n] = st.spot;
+                r.obs_src[n] = l.src[e];
+            }
         }
         __syncthreads();
     }
