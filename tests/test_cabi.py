@@ -92,3 +92,22 @@ def test_product_never_imports_the_oracle():
                 if re.search(r"\b(from|import)\s+oracle\b|fe_oracle|libfe_oracle", txt):
                     bad.append(os.path.join(root, f))
     assert not bad, bad
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md must map every symbol of the header to the reference code it replaces."""
+    doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
+    missing = [n for n in declared_symbols() if n not in doc]
+    assert not missing, f"INTEGRATION.md does not mention: {missing}"
+
+
+def test_header_cites_reference_lines_for_every_compute_entry_point():
+    text = open(HEADER).read()
+    blocks = re.findall(r"/\*(.*?)\*/\s*((?:int|int64_t|const char \*)\s*\*?fe_[a-z_]+\s*\([^;]*;(?:\s*(?:int|int64_t)\s+fe_[a-z_]+\s*\([^;]*;)*)", text, flags=re.S)
+    cited = {}
+    for comment, decls in blocks:
+        for name in re.findall(r"\b(fe_[a-z_]+)\s*\(", decls):
+            cited[name] = bool(re.search(r"TSE:\d+|\.py:\d+", comment))
+    housekeeping = {"fe_version", "fe_last_error", "fe_device_count", "fe_env_launch_info", "fe_env_destroy"}
+    need = [n for n in declared_symbols() if n not in housekeeping]
+    assert all(cited.get(n, False) for n in need), {n: cited.get(n) for n in need if not cited.get(n, False)}
