@@ -34,7 +34,7 @@ def needs_build() -> bool:
 def build(force: bool = False, verbose: bool = False) -> str:
     if force or needs_build():
         cmd = [HIPCC] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", LIB]
-        for knob in ("FE_MIN_WAVES_PER_EU", "FE_STORE_AUX", "FE_ROLLOUT_WAVES"):  # tuning experiments only
+        for knob in ("FE_MIN_WAVES_PER_EU", "FE_STORE_AUX", "FE_ROLLOUT_WAVES", "FE_ROLLOUT_NOPOLICY"):  # tuning experiments only
             if os.environ.get(knob):
                 cmd.insert(1, f"-D{knob}=" + os.environ[knob])
         if verbose:

@@ -614,6 +614,8 @@ struct SleeveReg {
     int64_t idx, spot;  // env_indices[n], env_spots[n][0]
     float cash, lng, sht;
     double margin;
+    int64_t obs_row;  // table row (idx * L + window start) of the observation the last step returned
+    double obs_pos;   // its position feature for this sleeve
 };
 
 // One step of phases 1/1b with the state in registers (the fused rollout): same arithmetic and the
@@ -645,6 +647,8 @@ __device__ __forceinline__ void account_keep(const Params &p, const TileLds &l, 
         sleeve_step(p, action, bar.x, bar.y, bar.z, bar.w, s);
         sdone = s.bankrupt | (nxt >= L) | (probe != probe);
         l.pos[e * A + a] = s.pos_obs;
+        st.obs_pos = s.pos_obs;
+        st.obs_row = st.idx * L + (s0 + W <= L ? s0 : L - W);
         if constexpr (!SINGLE) {
             l.rew[e * A + a] = s.rew;
             l.shr[e * A + a] = s.sht + s.lng;
@@ -803,6 +807,10 @@ __global__ __launch_bounds__(kBlock, FE_ROLLOUT_WAVES) void fe_rollout_linear_ke
         const int pairs = ebt * A;
         for (int k = 0; k < r.K; ++k) {
             // policy: one wavefront per (env, asset) pair of the tile
+#ifdef FE_ROLLOUT_NOPOLICY  /* diagnostic build: how long is a step without the policy? */
+            for (int q = tid; q < pairs; q += kBlock) s_act[q] = (float)r.bias;
+            if (false)
+#endif
             for (int q = wave; q < pairs; q += kBlock / 64) {
                 const int ee = SINGLE ? q : (int)fdiv((uint32_t)q, p.div_A);
                 const int aa = SINGLE ? 0 : q - ee * A;
@@ -844,6 +852,131 @@ __global__ __launch_bounds__(kBlock, FE_ROLLOUT_WAVES) void fe_rollout_linear_ke
             }
         }
         __syncthreads();
+    }
+}
+
+// ---- f2, table form: the linear policy as a precomputed indicator ----
+// For fixed weights the log-return part of the policy is a FIR filter over the day's series: one
+// number per (day, window start, asset).  fe_policy_table_kernel evaluates it once per weight update
+// (one wavefront per entry, the same lane/butterfly order as above over the four log-return
+// features), then a K-step rollout needs two 8-byte lookups per sleeve and step:
+//   action = clamp(bias + (table[row][a] + pos * wsum), -1, 1),  wsum = sum_j w[j][4] (same order).
+// The split of the sum is part of THIS form's contract (it rounds differently from the window form).
+__global__ __launch_bounds__(kBlock) void fe_policy_table_kernel(const Params p, const double *weights,
+                                                                double *table, double *wsum) {
+    const int A = p.A, W = p.W;
+    const int64_t L = p.L;
+    const int lane = threadIdx.x & 63;
+    const int64_t gw = (blockIdx.x * (int64_t)kBlock + threadIdx.x) >> 6, nw = ((int64_t)gridDim.x * kBlock) >> 6;
+    const int64_t total = p.D * L * A;
+    for (int64_t q = gw; q < total; q += nw) {
+        const int64_t row = q / A;
+        const int a = (int)(q - row * A);
+        const int64_t s = row % L;
+        double acc = 0.0;
+        if (s + W <= L) {
+            for (int j = lane; j < W; j += 64) {
+                const double4 v = *reinterpret_cast<const double4 *>(p.LR + ((row + j) * A + a) * 4);
+                const double *wr = weights + j * 5;
+                acc += v.x * wr[0];
+                acc += v.y * wr[1];
+                acc += v.z * wr[2];
+                acc += v.w * wr[3];
+            }
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) acc = acc + __shfl_xor(acc, m, 64);
+        } else {
+            acc = __longlong_as_double(0x7ff8000000000000ll);  // no window starts here
+        }
+        if (lane == 0) table[q] = acc;
+    }
+    if (gw == 0) {
+        double acc = 0.0;
+        for (int j = lane; j < W; j += 64) acc += weights[j * 5 + 4];
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc = acc + __shfl_xor(acc, m, 64);
+        if (lane == 0) wsum[0] = acc;
+    }
+}
+
+struct TableRolloutArgs {
+    const double *table;  // (D, L, A)
+    const double *wsum;   // (1)
+    double bias;
+    int32_t K;
+    int64_t *obs_src;
+    double *obs_pos;
+    float *actions_out;
+    double *rew_out;
+    int32_t *done_out;
+};
+
+__host__ __device__ inline size_t table_rollout_lds_bytes(int EB, int A) {
+    size_t S = (size_t)EB * A;
+    size_t b = (size_t)EB * 8 + S * 8 + S * 8 + S * 4 + S * 4 + (size_t)EB * 4;  // TileLds
+    b = (b + 7) & ~(size_t)7;
+    return ((b + (size_t)EB * 8) + 15) & ~(size_t)15;  // + redrawn day per env
+}
+
+template <bool SINGLE>
+__global__ __launch_bounds__(kBlock) void fe_rollout_table_kernel(const Params p, const TableRolloutArgs r) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const int S = EB * A;
+    const TileLds l = carve_lds(smem, EB, S);
+    size_t off = (size_t)EB * 8 + (size_t)S * 8 + (size_t)S * 8 + (size_t)S * 4 + (size_t)S * 4 + (size_t)EB * 4;
+    off = (off + 7) & ~(size_t)7;
+    int64_t *l_idx = reinterpret_cast<int64_t *>(smem + off);
+    const int tid = threadIdx.x;
+    const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
+    const int a = SINGLE ? 0 : tid - e * A;
+    const int64_t NA = p.N * A;
+    const double wsum = r.wsum[0];
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        const bool active = e < ebt;
+        const int64_t n = n0 + e;
+        const int64_t sl = n * A + a;
+        SleeveReg st;
+        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
+        st.obs_row = 0; st.obs_pos = 0.0;
+        if (active) {
+            st.idx = p.env_idx[n];
+            st.spot = p.spot0[n];
+            st.cash = p.cash[sl];
+            st.lng = p.lng[sl];
+            st.sht = p.sht[sl];
+            st.margin = p.margin[sl];
+            st.obs_row = r.obs_src[n] / (4 * (int64_t)A);
+            st.obs_pos = r.obs_pos[sl];
+        }
+        for (int k = 0; k < r.K; ++k) {
+            float act = 0.0f;
+            if (active) {  // the whole policy: two lookups, lane-private
+                double a64 = r.bias + (r.table[st.obs_row * A + a] + st.obs_pos * wsum);
+                a64 = a64 < -1.0 ? -1.0 : (a64 > 1.0 ? 1.0 : a64);
+                act = (float)a64;
+                if (r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
+            }
+            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
+                                 r.done_out + (int64_t)k * p.N);
+            if constexpr (!SINGLE) lds_barrier();  // LDS scratch of account_keep is reused next step
+        }
+        if (active) {
+            p.cash[sl] = st.cash;
+            p.lng[sl] = st.lng;
+            p.sht[sl] = st.sht;
+            p.margin[sl] = st.margin;
+            r.obs_pos[sl] = st.obs_pos;
+            if (a == 0) {
+                p.env_idx[n] = st.idx;
+                p.spot0[n] = st.spot;
+                r.obs_src[n] = st.obs_row * 4 * (int64_t)A;
+            }
+        }
+        if constexpr (!SINGLE) __syncthreads();
     }
 }
 
@@ -1244,6 +1377,48 @@ int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32
         hipLaunchKernelGGL(fe_rollout_linear_kernel<false>, g, b, lds, (hipStream_t)stream, p, r);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_linear launch");
+    return FE_OK;
+}
+
+int fe_policy_table(fe_env *env, const double *weights, double *table, double *wsum, void *stream) {
+    if (!env || !weights || !table || !wsum) return fail(FE_ERR_ARG, "fe_policy_table: null argument");
+    const Params &p = env->p;
+    const int64_t entries = p.D * p.L * p.A;
+    int64_t blocks = (entries * 64 + kBlock - 1) / kBlock;
+    if (blocks > 256 * 16) blocks = 256 * 16;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(fe_policy_table_kernel, dim3((unsigned)blocks), dim3(kBlock), 0, (hipStream_t)stream, p, weights,
+                       table, wsum);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_policy_table launch");
+    return FE_OK;
+}
+
+int fe_env_rollout_table(fe_env *env, const double *table, const double *wsum, double bias, int32_t K,
+                         int64_t *obs_src, double *obs_pos, float *actions_out, double *rewards_out,
+                         int32_t *dones_out, void *stream) {
+    if (!env || !table || !wsum || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
+        return fail(FE_ERR_ARG, "fe_env_rollout_table: bad argument");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_table: state not bound");
+    Params p = env->p;
+    // lane-private loop (no LDS traffic at one asset): full workgroups of sleeves
+    int64_t eb = kBlock / p.A > 0 ? kBlock / p.A : 1;
+    const char *ov = getenv("FE_TILE_ENVS");
+    if (ov && atoi(ov) > 0 && atoi(ov) < eb) eb = atoi(ov);
+    p.EB = (int)eb;
+    p.num_tiles = (p.N + eb - 1) / eb;
+    TableRolloutArgs r;
+    r.table = table; r.wsum = wsum; r.bias = bias; r.K = K; r.obs_src = obs_src; r.obs_pos = obs_pos;
+    r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
+    int64_t grid = p.num_tiles < 8 * 256 ? p.num_tiles : 8 * 256;
+    const size_t lds = table_rollout_lds_bytes(p.EB, p.A);
+    dim3 g((unsigned)grid), b(kBlock);
+    if (p.A == 1)
+        hipLaunchKernelGGL(fe_rollout_table_kernel<true>, g, b, lds, (hipStream_t)stream, p, r);
+    else
+        hipLaunchKernelGGL(fe_rollout_table_kernel<false>, g, b, lds, (hipStream_t)stream, p, r);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_table launch");
     return FE_OK;
 }
 

@@ -138,6 +138,23 @@ int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32
                           double *obs_pos, float *actions_out, double *rewards_out, int32_t *dones_out,
                           void *stream);
 
+/*
+ * Table form of the in-kernel linear policy.  For fixed weights the log-return part of the policy
+ * is an indicator of the day's series, like the reference's precomputed log-returns (TSE:179-194):
+ * fe_policy_table fills table (D, L, A) f64 with
+ *   table[d][s][a] = sum_j sum_{c<4} log_return[d][s+j][4a+c] * weights[j][c]   (NaN where s+W > L)
+ * and wsum[0] = sum_j weights[j][4], both in the 64-lane partial-sum + butterfly order above;
+ * fe_env_rollout_table then runs K steps with
+ *   action = clamp(bias + (table[row][a] + pos * wsum), -1, 1)
+ * i.e. two 8-byte lookups per sleeve and step instead of re-reading the window.  Same rollout-loop
+ * semantics and side effects as fe_env_rollout_linear (examples/time_series/
+ * PPO_LSTM_training_SPY.py:22-28); the split of the sum is part of this form's contract.
+ */
+int fe_policy_table(fe_env *env, const double *weights, double *table, double *wsum, void *stream);
+int fe_env_rollout_table(fe_env *env, const double *table, const double *wsum, double bias, int32_t K,
+                         int64_t *obs_src, double *obs_pos, float *actions_out, double *rewards_out,
+                         int32_t *dones_out, void *stream);
+
 /* env_indices[env] = day (the host half of TSE:510-513 when redraw_mode == 0). */
 int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream);
 

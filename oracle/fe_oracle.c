@@ -424,3 +424,61 @@ void fo_policy_linear(const double *obs, const double *weights, double bias, int
             actions_out[n * A + a] = (float)a64;
         }
 }
+
+/*
+ * f2, table form (fe_policy_table + fe_env_rollout_table): the log-return part of the linear
+ * policy as a per-(day, window start, asset) indicator table, same 64-partials + butterfly order
+ * over the four log-return features; wsum = sum_j w[j][4] in that order.
+ */
+static double butterfly64(double part[64]) {
+    for (int m = 32; m >= 1; m >>= 1) {
+        double nxt[64];
+        for (int l = 0; l < 64; ++l) nxt[l] = part[l] + part[l ^ m];
+        memcpy(part, nxt, sizeof(nxt));
+    }
+    return part[0];
+}
+
+void fo_policy_table(const double *LR, const double *weights, int64_t D, int64_t L, int32_t W, int32_t A,
+                     double *table, double *wsum) {
+    for (int64_t d = 0; d < D; ++d)
+        for (int64_t s = 0; s < L; ++s)
+            for (int32_t a = 0; a < A; ++a) {
+                double part[64];
+                if (s + W > L) {
+                    table[(d * L + s) * A + a] = NAN;
+                    continue;
+                }
+                for (int l = 0; l < 64; ++l) {
+                    double acc = 0.0;
+                    for (int32_t j = l; j < W; j += 64) {
+                        const double *row = LR + (((d * L + s + j) * (int64_t)A) + a) * 4;
+                        const double *wr = weights + (int64_t)j * 5;
+                        acc += row[0] * wr[0];
+                        acc += row[1] * wr[1];
+                        acc += row[2] * wr[2];
+                        acc += row[3] * wr[3];
+                    }
+                    part[l] = acc;
+                }
+                table[(d * L + s) * A + a] = butterfly64(part);
+            }
+    double part[64];
+    for (int l = 0; l < 64; ++l) {
+        double acc = 0.0;
+        for (int32_t j = l; j < W; j += 64) acc += weights[(int64_t)j * 5 + 4];
+        part[l] = acc;
+    }
+    wsum[0] = butterfly64(part);
+}
+
+/* actions of the table form for observations described by (row = idx*L + window start, pos) */
+void fo_policy_table_actions(const double *table, double wsum, double bias, const int64_t *obs_row,
+                             const double *obs_pos, int64_t N, int32_t A, float *actions_out) {
+    for (int64_t n = 0; n < N; ++n)
+        for (int32_t a = 0; a < A; ++a) {
+            double a64 = bias + (table[obs_row[n] * A + a] + obs_pos[n * A + a] * wsum);
+            a64 = a64 < -1.0 ? -1.0 : (a64 > 1.0 ? 1.0 : a64);
+            actions_out[n * A + a] = (float)a64;
+        }
+}

@@ -113,6 +113,28 @@ def policy_linear(obs: np.ndarray, weights: np.ndarray, bias: float) -> np.ndarr
     return out
 
 
+def policy_table(LR: np.ndarray, weights: np.ndarray, W: int):
+    """(table (D, L, A), wsum) of the table-form linear policy."""
+    LR = np.ascontiguousarray(LR, dtype=np.float64)
+    weights = np.ascontiguousarray(weights, dtype=np.float64)
+    D, L, c4 = LR.shape
+    A = c4 // 4
+    table = np.empty((D, L, A), dtype=np.float64)
+    wsum = np.empty(1, dtype=np.float64)
+    lib().fo_policy_table(_p(LR), _p(weights), C.c_int64(D), C.c_int64(L), C.c_int32(W), C.c_int32(A), _p(table), _p(wsum))
+    return table, float(wsum[0])
+
+
+def policy_table_actions(table: np.ndarray, wsum: float, bias: float, obs_row: np.ndarray, obs_pos: np.ndarray) -> np.ndarray:
+    obs_row = np.ascontiguousarray(obs_row, dtype=np.int64)
+    obs_pos = np.ascontiguousarray(obs_pos, dtype=np.float64)
+    N, A = obs_pos.shape
+    out = np.empty((N, A), dtype=np.float32)
+    lib().fo_policy_table_actions(_p(np.ascontiguousarray(table)), C.c_double(wsum), C.c_double(bias), _p(obs_row), _p(obs_pos),
+                                  C.c_int64(N), C.c_int32(A), _p(out))
+    return out
+
+
 class OracleEnv:
     """numpy-state mirror of TimeSeriesEnv driven by fo_step / fo_reset_obs."""
 

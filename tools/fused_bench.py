@@ -13,8 +13,8 @@ for cfg in [int(x) for x in (sys.argv[1:] or ["2"])]:
         else: os.environ.pop("FE_TILE_ENVS", None)
         env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", obs_buffers=1)
         w = torch.randn((W, 5), dtype=torch.float64) * 2
-        roll = FusedLinearRollout(env, w, 0.0)
-        K = 32
+        roll = FusedLinearRollout(env, w, 0.0, form=os.environ.get('FUSED_FORM', 'window'))
+        K = int(os.environ.get('FUSED_K', '32'))
         roll.run(K, record_actions=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
