@@ -39,6 +39,7 @@ SIGNATURES = {
     "fe_device_count": (C.c_int, []),
     "fe_env_create": (C.c_int, [C.POINTER(FeConfig), _vp, _vp, C.POINTER(_vp)]),
     "fe_env_bind_state": (C.c_int, [_vp] * 10),
+    "fe_env_bind_f32_table": (C.c_int, [_vp, _vp]),
     "fe_env_bind_stats": (C.c_int, [_vp, _vp, _vp, _vp]),
     "fe_env_reset_obs": (C.c_int, [_vp, _vp, _vp]),
     "fe_env_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),

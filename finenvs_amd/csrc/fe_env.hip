@@ -30,6 +30,7 @@
 #include <string.h>
 
 #include <new>
+#include <type_traits>
 
 #include "finenvs_amd.h"
 
@@ -92,6 +93,7 @@ __device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
 struct Params {
     const double *P;
     const double *LR;
+    const float *LR32;  // optional f32 copy of LR for f32 observations (fe_env_bind_f32_table)
     int64_t *env_idx;
     int64_t *spot0;
     float *cash;
@@ -465,7 +467,11 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
     const uint32_t WA = (uint32_t)p.W * (uint32_t)A;           // 32-byte table tuples per env
     const uint32_t tuples = (uint32_t)ebt * WA;
     for (uint32_t base = wave * TPI; base < tuples; base += 4 * TPI) {
-        double4 v[G];
+        // f32 observations read a pre-cast f32 copy of the table when one is bound: half the L2 traffic,
+        // same values ((float) of the f64 entry either way)
+        using TupleT = typename std::conditional<sizeof(OT) == 4, float4, double4>::type;
+        const bool narrow = sizeof(OT) == 4 && p.LR32 != nullptr;
+        TupleT v[G];
         double pz[G];
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
@@ -474,7 +480,16 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
             const uint32_t ee = fdiv(tc, p.div_WA);           // env within the tile
             const uint32_t r = tc - ee * WA;                  // (row j, asset a) = r / A, r % A
             const uint32_t aa = SINGLE ? 0u : r - fdiv(r, p.div_A) * (uint32_t)A;
-            v[gi] = *reinterpret_cast<const double4 *>(p.LR + l.src[ee] + 4u * r);
+            if constexpr (sizeof(OT) == 4) {
+                if (narrow) {
+                    v[gi] = *reinterpret_cast<const float4 *>(p.LR32 + l.src[ee] + 4u * r);
+                } else {
+                    const double4 d = *reinterpret_cast<const double4 *>(p.LR + l.src[ee] + 4u * r);
+                    v[gi] = make_float4((float)d.x, (float)d.y, (float)d.z, (float)d.w);
+                }
+            } else {
+                v[gi] = *reinterpret_cast<const double4 *>(p.LR + l.src[ee] + 4u * r);
+            }
             pz[gi] = l.pos[ee * A + aa];
         }
 #pragma unroll
@@ -1275,6 +1290,14 @@ int fe_env_bind_state(fe_env *env, int64_t *env_idx, int64_t *spot0, float *cash
     p.margin = margin; p.terminated = terminated; p.ep_ret = episode_returns;
     p.counters = reinterpret_cast<unsigned long long *>(counters);
     env->bound = true;
+    return FE_OK;
+}
+
+int fe_env_bind_f32_table(fe_env *env, const float *logret_f32) {
+    if (!env) return fail(FE_ERR_ARG, "fe_env_bind_f32_table: null env");
+    if (logret_f32 && !env->cfg.obs_is_f32)
+        return fail(FE_ERR_ARG, "fe_env_bind_f32_table: only meaningful with f32 observations");
+    env->p.LR32 = logret_f32;
     return FE_OK;
 }
 

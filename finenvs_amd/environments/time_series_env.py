@@ -248,6 +248,10 @@ class TimeSeriesEnv:
             handle, self.env_indices.data_ptr(), self._spot0.data_ptr(), self.cash.data_ptr(),
             self.long_shares.data_ptr(), self.short_shares.data_ptr(), self.margin.data_ptr(),
             self.terminated_episodes.data_ptr(), self.episode_returns.data_ptr(), self._counters.data_ptr()))
+        if self.obs_dtype == torch.float32:
+            # f32 observations stream from a pre-cast copy of the table (half the L2 reads, same values)
+            self._log_return_f32 = self.log_return_environments.float().contiguous()
+            _lib.check(self._lib.fe_env_bind_f32_table(handle, self._log_return_f32.data_ptr()))
         # observation ring: 0 = fresh tensor per call (reference semantics), k = k env-owned buffers
         self.obs_buffers = int(obs_buffers)
         self._obs_ring = [torch.empty((N, W, 5 * A), dtype=self.obs_dtype, device=dev) for _ in range(self.obs_buffers)]

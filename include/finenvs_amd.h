@@ -106,6 +106,14 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
                 void *stream);
 
 /*
+ * Optional, f32 observations only: an f32 copy (D, L, 4*A) of the log-return table, cast by the
+ * caller ((float) of every entry).  Observations then stream from it -- half the L2 traffic of the
+ * f64 table, identical values (TSE:423-445 followed by the callers' states.float(),
+ * finenvs/agents/PPO/PPO_agent.py:101).  NULL unbinds.
+ */
+int fe_env_bind_f32_table(fe_env *env, const float *logret_f32);
+
+/*
  * Optional episode statistics fused into fe_env_step: replaces the per-step
  * bookkeeping of the reference's agents (finenvs/agents/PPO/PPO_agent.py:120-132: running
  * return per env, returns of finished training episodes, the eval env's return -- and its

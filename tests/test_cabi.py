@@ -22,7 +22,7 @@ def lib():
 def declared_symbols():
     text = open(HEADER).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(fe_[a-z_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b(fe_[a-z0-9_]+)\s*\(", text)))
 
 
 def test_header_symbols_are_all_exported_and_bound(lib):
@@ -103,10 +103,10 @@ def test_integration_doc_names_every_entry_point():
 
 def test_header_cites_reference_lines_for_every_compute_entry_point():
     text = open(HEADER).read()
-    blocks = re.findall(r"/\*(.*?)\*/\s*((?:int|int64_t|const char \*)\s*\*?fe_[a-z_]+\s*\([^;]*;(?:\s*(?:int|int64_t)\s+fe_[a-z_]+\s*\([^;]*;)*)", text, flags=re.S)
+    blocks = re.findall(r"/\*(.*?)\*/\s*((?:int|int64_t|const char \*)\s*\*?fe_[a-z0-9_]+\s*\([^;]*;(?:\s*(?:int|int64_t)\s+fe_[a-z0-9_]+\s*\([^;]*;)*)", text, flags=re.S)
     cited = {}
     for comment, decls in blocks:
-        for name in re.findall(r"\b(fe_[a-z_]+)\s*\(", decls):
+        for name in re.findall(r"\b(fe_[a-z0-9_]+)\s*\(", decls):
             cited[name] = bool(re.search(r"TSE:\d+|\.py:\d+", comment))
     housekeeping = {"fe_version", "fe_last_error", "fe_device_count", "fe_env_launch_info", "fe_env_destroy"}
     need = [n for n in declared_symbols() if n not in housekeeping]
