@@ -192,3 +192,31 @@ def test_philox_known_answer():
         assert lib.fo_philox_u32(C.c_uint64(seed), C.c_uint64(ctr)) == philox(seed, ctr)
     days = [lib.fo_redraw_day(C.c_uint64(9), C.c_uint64(i), C.c_int64(64)) for i in range(2000)]
     assert min(days) == 0 and max(days) == 63
+
+
+def test_oracle_policy_forms_are_consistent():
+    """The two restated policy forms (window sum vs indicator table + position term) agree to rounding,
+    and the table is NaN exactly where no window can start."""
+    from finenvs_amd.data import synthetic
+
+    prices, day_id, _ = synthetic.synthetic_series(5, 2, 40, 3, 0.1)
+    W = 70 if False else 9
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    D, L, _ = P.shape
+    rng = np.random.default_rng(1)
+    weights = rng.normal(0, 2.0, (W, 5))
+    table, wsum = fo.policy_table(LR, weights, W)
+    assert table.shape == (D, L, 2)
+    assert np.isnan(table[:, L - W + 1:, :]).all() and np.isfinite(table[:, 0, :]).all()
+    assert wsum == pytest.approx(weights[:, 4].sum(), rel=1e-14)
+    env = fo.OracleEnv(P, LR, W, num_envs=11, evaluate=True)
+    obs = env.reset().copy()
+    for t in range(25):
+        a_win = fo.policy_linear(obs, weights, 0.1)
+        row = env.env_idx * L + env.spot0 if t == 0 else row_next
+        a_tab = fo.policy_table_actions(table, wsum, 0.1, row, obs[:, 0, 4::5].copy())
+        assert np.abs(a_win.astype(np.float64) - a_tab).max() < 1e-6
+        idx_pre, spot_pre = env.env_idx.copy(), env.spot0.copy()
+        obs, _, _, _ = env.step(a_win)
+        obs = obs.copy()
+        row_next = idx_pre * L + spot_pre + 1
