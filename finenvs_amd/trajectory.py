@@ -26,20 +26,27 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 class TrajectoryBuffer:
     def __init__(self, num_steps: int, num_envs: int, num_assets: int = 1, device: str = "cuda:0",
-                 host_rehearsal: bool = False):
+                 host_rehearsal: bool = False, capacity: Optional[int] = None):
+        """``capacity`` (>= num_envs, same on every rank) sizes the env axis of the buffers, so that ranks
+        owning shards of different sizes (N not divisible by the world size) can still exchange chunks with
+        one all-gather; ``join_shards`` drops the padding again."""
         self.T, self.N, self.A = int(num_steps), int(num_envs), int(num_assets)
+        self.C = int(capacity) if capacity is not None else self.N
+        if self.C < self.N:
+            raise ValueError("capacity must be >= num_envs")
         self.device = torch.device(device)
         if self.device.type != "cuda" and not host_rehearsal:
             raise RuntimeError("TrajectoryBuffer lives in HBM; host tensors are accepted only with host_rehearsal=True, "
                                "which exists to rehearse the all-gather plumbing over gloo (no kernels run there)")
-        T, N, A = self.T, self.N, self.A
+        T, N, A = self.T, self.C, self.A  # the env axis is laid out with `capacity` slots
         # one allocation per chunk, three typed views: [rewards f64 | actions f32 | dones i32];
         # two chunks so that a chunk can be in flight on the collective stream while the next fills
         self._nbytes = T * N * 8 + T * N * A * 4 + T * N * 4
         self._chunks = [torch.zeros((self._nbytes,), dtype=torch.uint8, device=self.device) for _ in range(2)]
         self._views = [self._typed(c) for c in self._chunks]
         # per-slot views, built once (tensor indexing costs microseconds of host time per call)
-        self._slots = [[(v[0][t], v[1][t], v[2][t]) for t in range(T)] for v in self._views]
+        n = self.N
+        self._slots = [[(v[0][t, :n], v[1][t, :n], v[2][t, :n]) for t in range(T)] for v in self._views]
         self._pending = [None, None]   # outstanding collective per chunk
         self._gathered = [None, None]  # its output buffer
         self._cur = 0
@@ -48,7 +55,7 @@ class TrajectoryBuffer:
         self._lib = _lib.load() if self._native else None
 
     def _typed(self, packed: torch.Tensor, lead: Tuple[int, ...] = ()):
-        T, N, A = self.T, self.N, self.A
+        T, N, A = self.T, self.C, self.A
         o1 = T * N * 8
         o2 = o1 + T * N * A * 4
         flat = packed.reshape(-1, self._nbytes) if lead else packed
@@ -63,15 +70,15 @@ class TrajectoryBuffer:
     # the chunk being filled
     @property
     def actions(self) -> torch.Tensor:
-        return self._views[self._cur][0]
+        return self._views[self._cur][0][:, : self.N]
 
     @property
     def rewards(self) -> torch.Tensor:
-        return self._views[self._cur][1]
+        return self._views[self._cur][1][:, : self.N]
 
     @property
     def dones(self) -> torch.Tensor:
-        return self._views[self._cur][2]
+        return self._views[self._cur][2][:, : self.N]
 
     @property
     def _packed(self) -> torch.Tensor:
@@ -99,9 +106,10 @@ class TrajectoryBuffer:
             if actions.dtype is not torch.float32:
                 actions = actions.float()
             st = self._stream()
+            sa, sr, sd = self._slots[self._cur][self.t]  # slot t starts at row t of the capacity-strided buffers
             _lib.check(self._lib.fe_traj_store(
-                self.t, self.N, self.A, actions.contiguous().data_ptr(), rewards.data_ptr(), dones.data_ptr(),
-                self.actions.data_ptr(), self.rewards.data_ptr(), self.dones.data_ptr(), st))
+                0, self.N, self.A, actions.contiguous().data_ptr(), rewards.data_ptr(), dones.data_ptr(),
+                sa.data_ptr(), sr.data_ptr(), sd.data_ptr(), st))
         else:  # host tensors: only the gloo rehearsal of the collective uses this
             self.actions[self.t].copy_(actions.reshape(self.N, self.A))
             self.rewards[self.t].copy_(rewards)
@@ -130,7 +138,10 @@ class TrajectoryBuffer:
         ret = torch.empty((T, N), dtype=torch.float32, device=self.device)
         adv = torch.empty((T, N), dtype=torch.float32, device=self.device)
         st = self._stream()
-        _lib.check(self._lib.fe_traj_returns(self.rewards.data_ptr(), self.dones.data_ptr(), values.data_ptr(),
+        rew, don = self.rewards[:T], self.dones[:T]
+        if self.C != self.N:  # the scan kernel wants dense (T, N) inputs
+            rew, don = rew.contiguous(), don.contiguous()
+        _lib.check(self._lib.fe_traj_returns(rew.data_ptr(), don.data_ptr(), values.data_ptr(),
                                              last_values.data_ptr(), T, N, float(gamma), ret.data_ptr(),
                                              adv.data_ptr(), st))
         return ret, adv
@@ -182,3 +193,16 @@ class TrajectoryBuffer:
     def drain(self) -> None:
         for i in (0, 1):
             self._wait(i)
+
+    @staticmethod
+    def join_shards(x: torch.Tensor, total_envs: int) -> torch.Tensor:
+        """(G, T, capacity, ...) gathered field -> (T, total_envs, ...): shards concatenated in rank order,
+        capacity padding dropped (shards as produced by ``shard_range``)."""
+        from .environments.time_series_env import shard_range
+
+        G = x.shape[0]
+        parts = []
+        for r in range(G):
+            lo, hi = shard_range(total_envs, r, G)
+            parts.append(x[r][:, : hi - lo])
+        return torch.cat(parts, dim=1)

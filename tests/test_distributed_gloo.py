@@ -12,7 +12,10 @@ import torch.multiprocessing as mp
 from finenvs_amd.environments.time_series_env import shard_range
 from finenvs_amd.trajectory import TrajectoryBuffer
 
-T, N_TOTAL, A = 5, 14, 3
+T, N_TOTAL, A = 5, 15, 3  # 15 envs over 2 ranks: shards of 8 and 7 (capacity 8)
+
+
+CAP = (N_TOTAL + 1) // 2
 
 
 def _free_port():
@@ -38,16 +41,21 @@ def _worker(rank, world, port, q):
     try:
         lo, hi = shard_range(N_TOTAL, rank, world)
         n = hi - lo
-        buf = TrajectoryBuffer(T, n, A, device="cpu", host_rehearsal=True)
+        buf = TrajectoryBuffer(T, n, A, device="cpu", host_rehearsal=True, capacity=CAP)
         _fill(buf, lo, n)
         assert buf.full()
         actions, rewards, dones, _ = buf.all_gather()
         ok = True
         for r in range(world):
             l2, h2 = shard_range(N_TOTAL, r, world)
-            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu", host_rehearsal=True)
+            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu", host_rehearsal=True, capacity=CAP)
             _fill(ref, l2, h2 - l2)
-            ok &= torch.equal(actions[r], ref.actions) and torch.equal(rewards[r], ref.rewards) and torch.equal(dones[r], ref.dones)
+            m = h2 - l2
+            ok &= torch.equal(actions[r][:, :m], ref.actions) and torch.equal(rewards[r][:, :m], ref.rewards) and torch.equal(dones[r][:, :m], ref.dones)
+        # join_shards drops the padding: (T, N_TOTAL) in global env order
+        joined = TrajectoryBuffer.join_shards(rewards, N_TOTAL)
+        gidx = torch.arange(N_TOTAL, dtype=torch.float64)
+        ok &= joined.shape == (T, N_TOTAL) and torch.equal(joined[2], gidx * 0.5 - 2)
         # the overlapped form used by bench.py: start, keep filling the other chunk, then collect
         buf.all_gather_async()
         assert len(buf) == 0
@@ -55,9 +63,10 @@ def _worker(rank, world, port, q):
         a2, r2, d2 = buf.wait_gathered()
         for r in range(world):
             l2, h2 = shard_range(N_TOTAL, r, world)
-            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu", host_rehearsal=True)
+            ref = TrajectoryBuffer(T, h2 - l2, A, device="cpu", host_rehearsal=True, capacity=CAP)
             _fill(ref, l2, h2 - l2)
-            ok &= torch.equal(a2[r], ref.actions) and torch.equal(r2[r], ref.rewards) and torch.equal(d2[r], ref.dones)
+            m = h2 - l2
+            ok &= torch.equal(a2[r][:, :m], ref.actions) and torch.equal(r2[r][:, :m], ref.rewards) and torch.equal(d2[r][:, :m], ref.dones)
         buf.all_gather_async()
         a3, r3, d3 = buf.wait_gathered()
         ok &= float(r3[rank][0, 0]) == (lo + 1000) * 0.5
