@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- env-steps/s of the fused TimeSeriesEnv.step() hot path on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W] [--config 2|3|4|1] [--no-cpu]
+    python bench.py [--gpus N --steps K --warmup W] [--config 2|3|4|5|1] [--repeats R] [--no-cpu] [--no-extra]
 
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
@@ -12,13 +12,26 @@ compact trajectory fields are all-gathered over RCCL.
 A "step" is one env.step(actions) over all envs of the workload: synthetic GBM minute
 bars (65 business days -> D=64 episodes of 390 bars), a ring of 8
 pre-generated uniform action tensors already resident in HBM, training mode, f64
-observations (the reference's dtype).  Prints ONE JSON line on rank 0.
+observations (the reference's dtype), a ring of two env-owned observation buffers (the
+rollout loop keeps the previous observation alive while the next is written).
+
+The timed region is EXACTLY K steps between two (barrier + synchronize) fences; it is repeated
+R times and the MEDIAN block is reported (min / max beside it), because one K-step block at
+64k envs is under a millisecond.  With N > 1 there are two legs per workload: steps with the
+asynchronous trajectory all-gather (the headline `value`) and steps without it.
+
+After the headline workload (BASELINE.json's "64k envs" configuration) the same process runs
+the larger BASELINE configs for a few steps each and reports them under "extra_configs" -- on
+one GPU configs 3 and 4 (the 1M-env north-star run), on N > 1 GPUs the per-GPU shard of
+config 5 (4M envs over 8 GPUs).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
 import argparse
+import gc
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -43,9 +56,18 @@ REFERENCE_CPU_QUOTED = {"value": 40497, "unit": "env-steps/s", "cores": 8,
                         "what": "hmomin/FinEnvs TimeSeriesEnv.step, torch 2.10 CPU, 65536 envs x W64, build container"}
 
 
-def algorithmic_bytes(W: int, A: int) -> int:
-    """obs write 8*W*5A + window read 8*W*4A + 84 B per sleeve + 36 B per env."""
+def survey_bytes(W: int, A: int) -> int:
+    """SURVEY 8(d) formula: obs write 8*W*5A + window read 8*W*4A + 84 B per sleeve + 36 B per env.
+    The window-read term is served by L2 / Infinity Cache (the tables are <= 64 MB), so this is NOT
+    an HBM byte count; it is reported beside the roofline, never as `achieved`."""
     return 72 * W * A + 84 * A + 36
+
+
+def hbm_bytes(W: int, A: int, obs_elem: int) -> int:
+    """Bytes per env-step that must cross HBM: the observation write (obs_elem*W*5A) + sleeve state
+    read/write, bar, NaN probe, action (84 B per sleeve) + indices, reward, done (36 B per env).
+    For f64 observations this is survey_bytes - 32*W*A; the PMC counters agree with it to 1 %."""
+    return obs_elem * W * 5 * A + 84 * A + 36
 
 
 def make_series(A: int):
@@ -88,10 +110,260 @@ def cpu_baseline(A: int, W: int, budget_s: float = 12.0):
             model = next(line.split(":", 1)[1].strip() for line in f if line.startswith("model name"))
     except Exception:  # noqa: BLE001
         pass
+    note = "" if A == 1 else "; NOTE the multi-asset sample is 4096 envs (cache-resident on the host, flatters the CPU)"
     return {"value": rate, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{k} steps of {n} envs x {A} assets x W{W} (oracle/fe_oracle.c, OpenMP {cores} threads, {el:.1f} s)",
+            "sample": f"{k} steps of {n} envs x {A} assets x W{W} (oracle/fe_oracle.c, OpenMP {cores} threads, {el:.1f} s){note}",
             "value_1thread": rate1, "cpu_model": model, "host_cpus_visible": os.cpu_count(),
             "reference_quoted": REFERENCE_CPU_QUOTED}
+
+
+def pmc_traffic(config: int, f32: bool):
+    """HBM traffic per launch from the committed PMC passes (profiles/hbm_traffic.json): rocprofv3 cannot
+    collect counters from inside this process, so the figure comes from the profiling run named in
+    `traffic_source` (same binary, same command line; tools/profile_box.sh)."""
+    path = os.path.join(REPO, "profiles", "hbm_traffic.json")
+    key = f"config{config}" + ("_f32" if f32 else "")
+    try:
+        ent = json.load(open(path)).get(key)
+    except Exception:  # noqa: BLE001
+        ent = None
+    if not ent:
+        return None, None
+    return ent.get("bytes_per_launch"), f"profiles/hbm_traffic.json[{key}], run tag {ent.get('tag')} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
+
+
+class Dist:
+    """torch.distributed plumbing; world == 1 needs none of it."""
+
+    def __init__(self, args):
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world != args.gpus and self.world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on device 0 + gloo
+        if os.environ.get("FE_BENCH_SINGLE_DEVICE") == "1":
+            self.local_rank = 0
+        self.backend = os.environ.get("FE_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        torch.cuda.set_device(self.local_rank)
+        self.dev = f"cuda:{self.local_rank}"
+        self.dist = None
+        if self.world > 1:
+            import datetime
+
+            import torch.distributed as dist
+
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            kw = {"timeout": datetime.timedelta(minutes=5)}
+            if self.backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device(self.dev), **kw)
+            else:
+                dist.init_process_group(self.backend, **kw)
+            self.dist = dist
+
+    def barrier(self):
+        if self.dist is not None:
+            self.dist.barrier()
+
+    def max_over_ranks(self, x: float) -> float:
+        if self.dist is None:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def all_ok(self, ok: bool) -> bool:
+        """True iff every rank says ok (so that no rank enters a collective loop alone)."""
+        if self.dist is None:
+            return ok
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return bool(t.item() > 0.5)
+
+
+def auto_repeats(repeats: int, steps: int, est_step_s: float) -> int:
+    if repeats > 0:
+        return repeats
+    # enough K-step blocks for ~0.15 s of timed work, between 5 and 40
+    return int(min(40, max(5, round(0.15 / max(steps * est_step_s, 1e-9)))))
+
+
+def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: int, with_cpu: bool):
+    """Build the env of one BASELINE config on this rank, time it, tear it down.  Returns the result dict
+    (on every rank; only rank 0 prints)."""
+    import finenvs_amd
+    from finenvs_amd import _lib as _fl
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    world, rank, dev = D.world, D.rank, D.dev
+    name, n_per_gpu, A, W = CONFIGS[config]
+    obs_elem = 4 if args.obs_f32 else 8
+    env = traj = actions = None
+    err = None
+    try:
+        prices, day_id, _ = make_series(A)
+        # config 4's observation is 153.6 GB: a single env-owned buffer (SURVEY section 7 "Capacity")
+        obs_bytes = n_per_gpu * W * 5 * A * obs_elem
+        obs_buffers = 2 if 2 * obs_bytes < 200e9 else 1
+        env = finenvs_amd.TimeSeriesEnv(
+            prices=prices, day_id=day_id, num_intervals=W, num_envs=n_per_gpu * world, rank=rank, world_size=world,
+            device_id=D.local_rank, redraw=args.redraw, seed=1234, obs_buffers=obs_buffers,
+            obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+        N = env.num_envs
+        g = torch.Generator(device=dev).manual_seed(7 + rank)
+        actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
+        # Compact trajectory fields live in a device buffer; the step kernel writes rewards/dones
+        # straight into slot t and the "policy" (the pre-generated action ring) owns the action slots,
+        # so storing a step costs nothing extra.  With N > 1 each full chunk is all-gathered (async).
+        traj = TrajectoryBuffer(TRAJ_T, N, A, device=dev)
+        for chunk in traj._views:  # ring period 8 divides TRAJ_T: slot t always holds ring[t % 8]
+            for t in range(TRAJ_T):
+                chunk[0][t].copy_(actions[t % 8])
+        torch.cuda.synchronize()
+    except Exception as exc:  # noqa: BLE001  (allocation / construction: before any collective)
+        err = f"{type(exc).__name__}: {exc}"
+    if not D.all_ok(err is None):
+        del env, traj, actions
+        gc.collect()
+        torch.cuda.empty_cache()
+        return {"workload": name, "config": config, "error": err or "another rank failed to build this workload"}
+
+    gather = [world > 1]  # mutable: the timed legs flip it
+
+    def one_step(i):
+        a, r, d = traj.next_slot()
+        obs, rew, done, _ = env.step(a, rewards_out=r, dones_out=d)
+        if traj.full():
+            if gather[0]:
+                traj.all_gather_async()  # overlaps the next TRAJ_T steps; waited for before reuse
+            else:
+                traj.clear()
+        return obs
+
+    roll = None
+    if args.graph:
+        if world > 1 or steps % 8:
+            sys.exit("--graph: single GPU only, and --steps must be a multiple of 8")
+        warmup = (warmup + 7) // 8 * 8
+        from finenvs_amd.rollout import GraphedRollout
+
+        roll = GraphedRollout(env, lambda obs, k: actions[k % 8], 8)
+        run_steps = lambda n: [roll.run() for _ in range(n // 8)]  # noqa: E731
+    else:
+        env.reset()
+        run_steps = lambda n: [one_step(i) for i in range(n)]  # noqa: E731
+
+    def fence():
+        traj.drain()  # outstanding gathers belong to the timed region
+        torch.cuda.synchronize()
+        D.barrier()
+        torch.cuda.synchronize()
+
+    def timed_blocks(r):
+        out = []
+        for _ in range(r):
+            fence()
+            t0 = time.perf_counter()
+            run_steps(steps)
+            fence()
+            out.append(D.max_over_ranks(time.perf_counter() - t0))
+        return out
+
+    run_steps(warmup)
+    fence()
+    t0 = time.perf_counter()
+    run_steps(min(steps, 8))
+    fence()
+    est = D.max_over_ranks(time.perf_counter() - t0) / min(steps, 8)
+    R = auto_repeats(repeats, steps, est)
+    legs = {}
+    if world > 1:
+        gather[0] = True
+        run_steps(TRAJ_T)  # one chunk in flight before the timed blocks
+        legs["with_all_gather"] = timed_blocks(R)
+        fence()
+        gather[0] = False
+        traj.clear()
+        legs["no_all_gather"] = timed_blocks(R)
+        head = legs["with_all_gather"]
+    else:
+        legs["single_gpu"] = timed_blocks(R)
+        head = legs["single_gpu"]
+    block = statistics.median(head)
+
+    # Kernel duration for the roofline: k2 launches issued straight through the C ABI (preallocated
+    # outputs, no per-step Python work) so the queue never drains, bracketed by ONE pair of HIP events on
+    # the launch stream (torch's current stream is the stream the C ABI launches on); the average interval
+    # = kernel + the ~1.5 us launch boundary.
+    k2 = min(max(steps, 20), 400)
+    stream = torch.cuda.current_stream().cuda_stream
+    obs_b = [t.data_ptr() for t in env._obs_ring]  # same ring as the timed region (keeps the HBM/MALL regime)
+    nb = len(obs_b)
+    rew_b = torch.empty((N,), dtype=torch.float64, device=dev)
+    done_b = torch.empty((N,), dtype=torch.int32, device=dev)
+    aptr = [a.data_ptr() for a in actions]
+    fn, h = env._step_fn, env._handle_v
+    kern = []
+    for _ in range(3):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(k2):
+            rc = fn(h, aptr[i % 8], obs_b[i % nb], rew_b.data_ptr(), done_b.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        _fl.check(rc)
+        kern.append(e0.elapsed_time(e1) / k2)
+    kern_ms = statistics.median(kern)
+
+    total_envs = env.global_num_envs if world > 1 else N
+    Bh = hbm_bytes(W, A, obs_elem)
+    Bs = survey_bytes(W, A) - (4 * W * 5 * A if args.obs_f32 else 0)
+    l2_read = (16 if args.obs_f32 else 32) * W * A  # window re-read per env-step, served by L2 / Infinity Cache
+    achieved = Bh * N / (kern_ms * 1e-3) / 1e9
+    traffic, traffic_source = pmc_traffic(config, args.obs_f32)
+    res = {
+        "workload": name, "config": config,
+        "value": total_envs * steps / block,
+        "ms_per_step": block / steps * 1e3,
+        "steps": steps, "warmup": warmup,
+        "envs_per_gpu": N, "num_assets": A, "window": W, "obs_buffers": obs_buffers,
+        "launch": env.launch_info(),
+        "launch_mode": "hipGraph x8 steps" if args.graph else "eager, one launch per step",
+        "repeats": {name_: {"blocks": len(v), "ms_per_step_median": statistics.median(v) / steps * 1e3,
+                            "ms_per_step_min": min(v) / steps * 1e3, "ms_per_step_max": max(v) / steps * 1e3,
+                            "value_median": total_envs * steps / statistics.median(v)}
+                    for name_, v in legs.items()},
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
+            "kernel": "fe_env_kernel (fused step)", "kernel_ms": kern_ms,
+            "kernel_ms_runs": kern, "kernel_launches_per_run": k2,
+            # `achieved` counts only bytes that must cross HBM (observation write + state + outputs):
+            "hbm_bytes_per_env_step": Bh, "units_per_launch": N,
+            # the window re-read of the SURVEY 8(d) formula comes from L2 / Infinity Cache, reported apart:
+            "l2_read_bytes_per_env_step": l2_read, "l2_GBps": l2_read * N / (kern_ms * 1e-3) / 1e9,
+            "survey_8d_bytes_per_env_step": Bs,
+            # whole-job check: HBM bytes / wall ms_per_step (must stay below the peak as well)
+            "achieved_wall": Bh * N / (block / steps) / 1e9,
+        },
+    }
+    if world > 1:
+        res["multi_gpu"] = {
+            "ranks_seen": D.dist.get_world_size(), "collective_backend": D.backend,
+            "trajectory_slots": TRAJ_T, "all_gather_every_steps": TRAJ_T,
+            "packed_bytes_per_rank_per_chunk": traj._nbytes,
+            "gathered_bytes_per_rank_per_chunk": traj._nbytes * world,
+            "value_with_all_gather": res["repeats"]["with_all_gather"]["value_median"],
+            "value_no_all_gather": res["repeats"]["no_all_gather"]["value_median"],
+        }
+    if with_cpu and rank == 0:
+        res["cpu_baseline"] = cpu_baseline(A, W)
+    fence()
+    del env, traj, actions, roll, rew_b, done_b, obs_b
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
 
 
 def main():
@@ -100,169 +372,61 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
+    ap.add_argument("--repeats", type=int, default=0, help="timed K-step blocks (0 = auto: ~0.15 s of timed work, 5..40)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs")
     ap.add_argument("--redraw", default="device", choices=["device", "torch"])
     ap.add_argument("--obs-f32", action="store_true", help="f32 observations (NOT the reference dtype; extra mode)")
     ap.add_argument("--graph", action="store_true", help="replay the 8-action ring as one hipGraph per 8 steps")
     args = ap.parse_args()
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
-    import torch.distributed as dist
-
-    # rehearsal knobs for a one-GPU box (never set by the driver): all ranks on device 0 + gloo
-    if os.environ.get("FE_BENCH_SINGLE_DEVICE") == "1":
-        local_rank = 0
-    backend = os.environ.get("FE_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
-    torch.cuda.set_device(local_rank)
-    dev = f"cuda:{local_rank}"
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(dev))
-        else:
-            dist.init_process_group(backend)
-
-    import finenvs_amd
-    from finenvs_amd.trajectory import TrajectoryBuffer
-
-    name, n_per_gpu, A, W = CONFIGS[args.config]
-    prices, day_id, _ = make_series(A)
-    # config 4's observation is 153.6 GB: a single env-owned buffer (SURVEY section 7 "Capacity")
-    obs_bytes = n_per_gpu * W * 5 * A * (4 if args.obs_f32 else 8)
-    obs_buffers = 2 if 2 * obs_bytes < 200e9 else 1
-    env = finenvs_amd.TimeSeriesEnv(
-        prices=prices, day_id=day_id, num_intervals=W, num_envs=n_per_gpu * world, rank=rank, world_size=world,
-        device_id=local_rank, redraw=args.redraw, seed=1234, obs_buffers=obs_buffers,
-        obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
-    N = env.num_envs
-    g = torch.Generator(device=dev).manual_seed(7 + rank)
-    actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
-    # Compact trajectory fields live in a device buffer; the step kernel writes rewards/dones
-    # straight into slot t and the "policy" (the pre-generated action ring) owns the action slots,
-    # so storing a step costs nothing extra.  With N > 1 each full chunk is all-gathered (async).
-    traj = TrajectoryBuffer(TRAJ_T, N, A, device=dev)
-    for chunk in traj._views:  # ring period 8 divides TRAJ_T: slot t always holds ring[t % 8]
-        for t in range(TRAJ_T):
-            chunk[0][t].copy_(actions[t % 8])
-
-    def one_step(i):
-        a, r, d = traj.next_slot()
-        obs, rew, done, _ = env.step(a, rewards_out=r, dones_out=d)
-        if traj.full():
-            if world > 1:
-                traj.all_gather_async()  # overlaps the next TRAJ_T steps; waited for before reuse
-            else:
-                traj.clear()
-        return obs
-
-    roll = None
-    if args.graph:
-        if world > 1 or args.steps % 8:
-            sys.exit("--graph: single GPU only, and --steps must be a multiple of 8")
-        args.warmup = (args.warmup + 7) // 8 * 8
-        from finenvs_amd.rollout import GraphedRollout
-
-        roll = GraphedRollout(env, lambda obs, k: actions[k % 8], 8)
-        run_steps = lambda n: [roll.run() for _ in range(n // 8)]
-    else:
-        env.reset()
-        run_steps = lambda n: [one_step(i) for i in range(n)]
-    run_steps(args.warmup)
-
-    def fence():
-        traj.drain()  # outstanding gathers belong to the timed region
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    fence()
-    t0 = time.perf_counter()
-    run_steps(args.steps)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # Kernel duration for the roofline: a second pass of k2 launches issued straight through the C ABI
-    # (preallocated outputs, no per-step Python work) so the queue never drains, bracketed by ONE pair of
-    # HIP events on the launch stream; the average interval = kernel + the ~1.5 us launch boundary.
-    from finenvs_amd import _lib as _fl
-
-    k2 = min(max(args.steps, 20), 400)
-    stream = torch.cuda.current_stream().cuda_stream
-    obs_b = [t.data_ptr() for t in env._obs_ring]  # same ring as the timed region (keeps the HBM/MALL regime)
-    nb = len(obs_b)
-    rew_b = torch.empty((N,), dtype=torch.float64, device=dev)
-    done_b = torch.empty((N,), dtype=torch.int32, device=dev)
-    aptr = [a.data_ptr() for a in actions]
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    fn, h = env._step_fn, env._handle_v
-    torch.cuda.synchronize()
-    e0.record()
-    for i in range(k2):
-        rc = fn(h, aptr[i % 8], obs_b[i % nb], rew_b.data_ptr(), done_b.data_ptr(), stream)
-    e1.record()
-    torch.cuda.synchronize()
-    _fl.check(rc)
-    kern_ms = e0.elapsed_time(e1) / k2
-
-    if rank == 0:
-        total_envs = N * world if world == 1 else env.global_num_envs
-        B = algorithmic_bytes(W, A) if not args.obs_f32 else algorithmic_bytes(W, A) - 4 * W * 5 * A
-        achieved = B * N / (kern_ms * 1e-3) / 1e9
-        Bc = B - 8 * W * 4 * A  # window reads are served by L2 / Infinity Cache (tables are <= 64 MB)
-        traffic = None
-        tpath = os.path.join(REPO, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
+    D = Dist(args)
+    head = run_workload(args.config, args, D, args.steps, args.warmup, args.repeats,
+                        with_cpu=(not args.no_cpu and D.world == 1))
+    if "error" in head:
+        sys.exit(f"bench.py: headline workload failed: {head['error']}")
+    extras = []
+    if not args.no_extra and not args.graph and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
+        wanted = ([3, 4] if D.world == 1 else [5])
+        for c in wanted:
+            if c == args.config:
+                continue
+            k = min(args.steps, 20)
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get(f"config{args.config}", {}).get("bytes_per_launch")
-            except Exception:  # noqa: BLE001
-                traffic = None
+                extras.append(run_workload(c, args, D, k, min(args.warmup, 5), 3, with_cpu=False))
+            except Exception as exc:  # noqa: BLE001
+                extras.append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
+                break
+
+    if D.rank == 0:
         out = {
             "metric": "env-steps/sec",
-            "value": total_envs * args.steps / elapsed,
+            "value": head["value"],
             "unit": "env-steps/s",
-            "n_gpus": world,
+            "n_gpus": D.world,
             "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
+            "warmup": head["warmup"],
+            "ms_per_step": head["ms_per_step"],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32" if args.obs_f32 else "f64",
             "data": "synthetic",
-            "config": {"workload": name, "envs_per_gpu": N, "num_assets": A, "window": W,
-                       "obs_buffers": obs_buffers, "eval_redraw": args.redraw,
-                       "launch_mode": "hipGraph x8 steps" if args.graph else "eager, one launch per step",
-                       "launch": env.launch_info(),
-                       "trajectory_slots": TRAJ_T, "trajectory_all_gather_every": TRAJ_T if world > 1 else None,
-                       "collective_backend": (backend if world > 1 else None)},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic,
-                         "kernel": "fe_env_kernel (fused step)", "kernel_ms": kern_ms,
-                         "algorithmic_bytes_per_env_step": B, "units_per_launch": N,
-                         # the part of B that cannot come from cache: observation + state + outputs
-                         "compulsory_hbm_bytes_per_env_step": Bc,
-                         "achieved_compulsory": Bc * N / (kern_ms * 1e-3) / 1e9,
-                         "frac_compulsory": Bc * N / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS},
+            "config": {"workload": head["workload"], "envs_per_gpu": head["envs_per_gpu"],
+                       "num_assets": head["num_assets"], "window": head["window"],
+                       "obs_buffers": head["obs_buffers"], "eval_redraw": args.redraw,
+                       "launch_mode": head["launch_mode"], "launch": head["launch"],
+                       "timed_region": "median of R blocks of exactly `steps` steps, each between (barrier + synchronize) fences, max over ranks per block"},
+            "repeats": head["repeats"],
+            "roofline": head["roofline"],
+            "cpu_baseline": head.get("cpu_baseline"),
+            "multi_gpu": head.get("multi_gpu"),
+            "extra_configs": [{k: v for k, v in e.items() if k != "cpu_baseline"} for e in extras],
         }
-        if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(A, W)
-        else:
-            out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        print(json.dumps(out), flush=True)
+    if D.dist is not None:
+        D.barrier()
+        D.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -43,7 +43,8 @@ def main(envs=4096, window=4, iters=8, steps=16, graph=False, hidden=64, seed=0)
     torch.manual_seed(seed)
     prices, day_id, _ = synthetic.synthetic_series(12, 1, 390, 1234)
     env = TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=window, num_envs=envs, redraw="device", seed=seed,
-                        obs_dtype=torch.float32)  # the agents call states.float() anyway (PPO_agent.py:101)
+                        obs_dtype=torch.float32,  # the agents call states.float() anyway (PPO_agent.py:101)
+                        obs_buffers=2)            # opt-in ring: this loop never keeps an observation for more than one step
     args = env.get_env_args()
     policy = TinyLSTMPolicy(args["num_observations"], hidden, args["num_actions"]).to(env.device)
     buffer = TrajectoryBuffer(steps, envs, env.num_assets, device=env.device)

@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfinenvs_amd.so")
 
-FE_ABI_VERSION = 1
+FE_ABI_VERSION = 2
 FE_MAX_ASSETS = 256
 
 
@@ -51,7 +51,12 @@ SIGNATURES = {
     "fe_env_set_day": (C.c_int, [_vp, _i64, _i64, _vp]),
     "fe_env_launch_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "fe_env_destroy": (C.c_int, [_vp]),
+    "fe_env_set_launch": (C.c_int, [_vp, _i32, _i32, _i32]),
+    "fe_build_tag": (C.c_char_p, []),
+    "fe_env_device": (C.c_int, [_vp]),
+    "fe_env_logret": (_vp, [_vp]),
     "fe_build_logret": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "fe_build_logret_tables": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp]),
     "fe_build_tables": (C.c_int, [_vp, _vp, _vp, _i64, _i64, _i32, _vp, _vp]),
     "fe_traj_store": (C.c_int, [_i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_traj_returns": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.c_double, _vp, _vp, _vp]),
@@ -89,6 +94,10 @@ def load(path: Optional[str] = None) -> C.CDLL:
         fn.argtypes = args
     if lib.fe_version() != FE_ABI_VERSION:
         raise FinEnvsNativeError(f"ABI mismatch: library {lib.fe_version()} != binding {FE_ABI_VERSION}")
+    tag = lib.fe_build_tag()
+    if path is None and tag:
+        raise FinEnvsNativeError(f"{p} is an experiment build ({tag.decode()}); rebuild the product library "
+                                 "(python -m finenvs_amd.csrc.build --force) or load variants by explicit path")
     if path is None:
         _lib = lib
     return lib

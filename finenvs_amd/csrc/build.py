@@ -32,15 +32,37 @@ def needs_build() -> bool:
 
 
 def build(force: bool = False, verbose: bool = False) -> str:
+    """The product library.  Takes NO tuning knobs from the environment: what is loaded by default is
+    always the default build (experiments go through build_variant and an explicit path)."""
     if force or needs_build():
-        cmd = [HIPCC] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", LIB]
-        for knob in ("FE_MIN_WAVES_PER_EU", "FE_STORE_AUX", "FE_ROLLOUT_WAVES", "FE_ROLLOUT_NOPOLICY"):  # tuning experiments only
-            if os.environ.get(knob):
-                cmd.insert(1, f"-D{knob}=" + os.environ[knob])
+        cmd = [HIPCC] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)
+        os.replace(LIB + ".tmp", LIB)  # never leave a half-written library behind
     return LIB
+
+
+VARIANT_KNOBS = ("FE_MIN_WAVES_PER_EU", "FE_STORE_AUX", "FE_ROLLOUT_WAVES", "FE_ROLLOUT_NOPOLICY", "FE_STEP_VARIANT")
+
+
+def build_variant(tag: str, defines: dict, verbose: bool = False) -> str:
+    """An experiment build: csrc/variants/libfinenvs_amd.<tag>.so with the given -D set and
+    FE_BUILD_TAG = "<tag>:<defines>".  _lib.load() refuses a tagged library unless its path is passed
+    explicitly (_lib.load(path)), so an interrupted experiment can never become the product."""
+    for k in defines:
+        if k not in VARIANT_KNOBS:
+            raise ValueError(f"unknown knob {k}; known: {VARIANT_KNOBS}")
+    out_dir = os.path.join(HERE, "variants")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, f"libfinenvs_amd.{tag}.so")
+    desc = tag + ":" + ",".join(f"{k}={v}" for k, v in sorted(defines.items()))
+    cmd = [HIPCC] + FLAGS + [f"-D{k}={v}" for k, v in defines.items()] + [f'-DFE_BUILD_TAG="{desc}"']
+    if verbose:
+        cmd.append("-Rpass-analysis=kernel-resource-usage")
+    cmd += [os.path.join(HERE, s) for s in SOURCES] + ["-o", out]
+    subprocess.check_call(cmd)
+    return out
 
 
 if __name__ == "__main__":

@@ -50,6 +50,11 @@ constexpr int kBlock = 256;
 // measured at 1M envs x 30 assets (tools/store_policy_box.sh) FETCH_SIZE 6.9 GiB -> 0.4 GiB per
 // launch and 26.4 -> 25.0 ms; sc1 (16) gives the same fetch reduction but 25.6 ms; no effect at 1 asset.
 // -1 = plain everywhere; >= 0 = buffer stores with that aux everywhere (experiments).
+// "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their
+// -D set here and are only ever loaded by explicit path
+#ifndef FE_BUILD_TAG
+#define FE_BUILD_TAG ""
+#endif
 #ifndef FE_STORE_AUX
 #define FE_STORE_AUX -2
 #endif
@@ -1055,6 +1060,28 @@ __global__ __launch_bounds__(kBlock) void fe_logret_kernel(const double *__restr
     }
 }
 
+// ---- a18 on the padded (D, L, 4A) price table, for fe_env_create(logret = NULL) ----
+// Same transform per row; the previous close of a day's row 0 lies outside its slice, so row 0 takes
+// the rule the reference applies to the first row of the series (open over open = 0, TSE:188-190).
+// NaN padding rows stay NaN (log of NaN).
+__global__ __launch_bounds__(kBlock) void fe_logret_tables_kernel(const double *__restrict__ P,
+                                                                  double *__restrict__ out, int64_t D, int64_t L,
+                                                                  int32_t A) {
+    const int64_t total = D * L * A;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t row = i / A;
+        const int64_t r = row % L;
+        const double4 p = *reinterpret_cast<const double4 *>(P + 4 * i);
+        const double prev = (r == 0) ? p.x : P[4 * (i - A) + 3];
+        double4 o;
+        o.x = 100.0 * log(p.x / prev);
+        o.y = 100.0 * log(p.y / p.x);
+        o.z = 100.0 * log(p.z / p.x);
+        o.w = 100.0 * log(p.w / p.x);
+        *reinterpret_cast<double4 *>(out + 4 * i) = o;
+    }
+}
+
 // ---- a19: per-day slices, NaN-padded, TSE:196-216 ----
 __global__ __launch_bounds__(kBlock) void fe_tables_kernel(const double *__restrict__ series,
                                                            const int64_t *__restrict__ starts,
@@ -1128,7 +1155,47 @@ struct fe_env {
     int vec;  // observation elements per 16-byte store (1 when the env size is odd)
     size_t lds;
     bool bound;
+    int cus;              // compute units of that device
+    int tile_override, grid_override, rollout_tile_override;  // fe_env_set_launch (tuning), 0 = automatic
+    int device;           // HIP device the tables live on; every launch runs there
+    double *owned_logret; // log-return table computed by fe_env_create(logret = NULL), else null
 };
+
+// Makes the env's device current for the duration of a call and restores the caller's device
+// afterwards: the reference's `device_id` argument works without torch.cuda.set_device (TSE:28, 45),
+// so a process driving several envs on several GPUs must not have to juggle the current device.
+struct DeviceGuard {
+    int prev = -1;
+    bool switched = false;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        if (device < 0) {
+            err = hipErrorInvalidDevicePointer;
+            return;
+        }
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) {
+            err = hipSetDevice(device);
+            switched = err == hipSuccess;
+        }
+    }
+    ~DeviceGuard() {
+        if (switched) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+
+// Device a caller-owned pointer lives on (-1 if it is not device memory).
+static int device_of(const void *ptr) {
+    hipPointerAttribute_t attr;
+    if (hipPointerGetAttributes(&attr, ptr) != hipSuccess) {
+        (void)hipGetLastError();
+        return -1;
+    }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged) return -1;
+    return attr.device;
+}
 
 // The kernel instantiation a given env dispatches to (shared by launch and occupancy query).
 template <bool RESET_ONLY>
@@ -1151,9 +1218,49 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     p.rew = rewards;
     p.done = dones;
     void *args[] = {&p};
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     hipError_t he = hipLaunchKernel(kernel_for<RESET_ONLY>(env->cfg.obs_is_f32 != 0, env->vec, p.A == 1),
                                     dim3(env->grid), dim3(kBlock), args, env->lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");
+    return FE_OK;
+}
+
+// Launch geometry of the step / reset kernels: tile size EB, tile count, grid, dynamic LDS.
+static int configure_launch(fe_env *env) {
+    const fe_config &cfg = env->cfg;
+    const int A = cfg.A;
+    const void *kern = kernel_for<false>(cfg.obs_is_f32 != 0, env->vec, A == 1);
+    // How many workgroups the chip holds at once for this kernel variant (registers + LDS).
+    const int64_t cap = kBlock / A > 0 ? kBlock / A : 1;  // one sleeve per lane in phase 1
+    int per_cu = 0;
+    hipError_t he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes((int)cap, A));
+    if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    int64_t resident = (int64_t)env->cus * per_cu;
+    if (resident > 8) resident -= resident % 8;  // keeps tile % 8 (the XCD label) constant per workgroup
+    // Tile = EB consecutive envs.  Aim for ~8/3 tiles per resident workgroup: measured on
+    // MI355X (tools/sweep_tiles.py, 64k envs) a few short tiles per workgroup beat one long
+    // tile (workgroups drift apart, so phase 1 of one hides under phase 2 of its CU-mates).
+    int64_t EB = (3 * cfg.N + 4 * resident) / (8 * resident);
+    if (EB < 1) EB = 1;
+    if (EB > cap) EB = cap;
+    if (env->tile_override > 0) EB = env->tile_override < cap ? env->tile_override : cap;
+    const int64_t num_tiles = (cfg.N + EB - 1) / EB;
+    // the LDS footprint depends on EB: ask again with the real size before fixing the grid
+    he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes((int)EB, A));
+    if (he == hipSuccess && per_cu >= 1) {
+        if (per_cu > 8) per_cu = 8;
+        resident = (int64_t)env->cus * per_cu;
+        if (resident > 8) resident -= resident % 8;
+    }
+    int64_t grid = num_tiles < resident ? num_tiles : resident;
+    if (env->grid_override > 0) grid = env->grid_override;
+    env->grid = (int)grid;
+    env->lds = lds_bytes((int)EB, A);
+    env->p.EB = (int)EB;
+    env->p.num_tiles = num_tiles;
     return FE_OK;
 }
 
@@ -1183,7 +1290,7 @@ int fe_device_count(void) {
 
 int fe_env_create(const fe_config *cfg, const double *prices, const double *logret, fe_env **out) {
     if (!cfg || !out) return fail(FE_ERR_ARG, "fe_env_create: null argument");
-    if (!prices || !logret) return fail(FE_ERR_ARG, "fe_env_create: prices and logret tables are required");
+    if (!prices) return fail(FE_ERR_ARG, "fe_env_create: the price table is required");
     if (cfg->N < 1 || cfg->D < 1) return fail(FE_ERR_ARG, "fe_env_create: N=%lld D=%lld must be >= 1", (long long)cfg->N, (long long)cfg->D);
     if (cfg->W < 1 || cfg->L <= cfg->W)
         return fail(FE_ERR_ARG, "fe_env_create: need 1 <= W < L (W=%lld, L=%lld)", (long long)cfg->W, (long long)cfg->L);
@@ -1200,63 +1307,62 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
         (void)hipGetLastError();
         return fail(FE_ERR_HIP, "fe_env_create: no HIP device (this library has no CPU path)");
     }
-    int dev = 0;
+    // the env lives where its tables live, whatever the caller's current device is
+    const int dev = device_of(prices);
+    if (dev < 0 || dev >= ndev) return fail(FE_ERR_ARG, "fe_env_create: prices is not a device pointer");
+    if (logret && device_of(logret) != dev)
+        return fail(FE_ERR_ARG, "fe_env_create: prices and logret live on different devices");
+    DeviceGuard guard(dev);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     hipDeviceProp_t prop;
-    if ((he = hipGetDevice(&dev)) != hipSuccess) return hip_fail(he, "hipGetDevice");
     if ((he = hipGetDeviceProperties(&prop, dev)) != hipSuccess) return hip_fail(he, "hipGetDeviceProperties");
 
     fe_env *env = new (std::nothrow) fe_env();
     if (!env) return fail(FE_ERR_ARG, "fe_env_create: out of host memory");
     env->cfg = *cfg;
     env->bound = false;
+    env->device = dev;
+    env->owned_logret = nullptr;
+    if (!logret) {
+        // logret = NULL: compute the table from the prices (the one allocation this library owns)
+        const int64_t tuples = cfg->D * cfg->L * (int64_t)cfg->A;
+        if ((he = hipMalloc(&env->owned_logret, (size_t)tuples * 32)) != hipSuccess) {
+            delete env;
+            return hip_fail(he, "fe_env_create: hipMalloc(logret)");
+        }
+        hipLaunchKernelGGL(fe_logret_tables_kernel, dim3(grid_for(tuples)), dim3(kBlock), 0, (hipStream_t) nullptr,
+                           prices, env->owned_logret, cfg->D, cfg->L, cfg->A);
+        he = hipGetLastError();
+        if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
+        if (he != hipSuccess) {
+            (void)hipFree(env->owned_logret);
+            delete env;
+            return hip_fail(he, "fe_env_create: log-return table");
+        }
+        logret = env->owned_logret;
+    }
     const int A = cfg->A;
     const int elem_bytes = cfg->obs_is_f32 ? 4 : 8;
     int vec = 16 / elem_bytes;
     while (vec > 1 && env_elems % vec != 0) vec /= 2;
     env->vec = vec;
-    // How many workgroups the chip holds at once for this kernel variant (registers + LDS).
-    const int64_t cap = kBlock / A > 0 ? kBlock / A : 1;  // one sleeve per lane in phase 1
-    int per_cu = 0;
-    he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_for<false>(cfg->obs_is_f32 != 0, vec, A == 1),
-                                                      kBlock, lds_bytes((int)cap, A));
-    if (he != hipSuccess) {
-        delete env;
-        return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
-    }
-    if (per_cu < 1) per_cu = 1;
-    if (per_cu > 8) per_cu = 8;
-    int64_t resident = (int64_t)prop.multiProcessorCount * per_cu;
-    if (resident > 8) resident -= resident % 8;  // keeps tile % 8 (the XCD label) constant per workgroup
-    // Tile = EB consecutive envs.  Aim for ~8/3 tiles per resident workgroup: measured on
-    // MI355X (tools/sweep_tiles.py, 64k envs) a few short tiles per workgroup beat one long
-    // tile (workgroups drift apart, so phase 1 of one hides under phase 2 of its CU-mates).
-    int64_t EB = (3 * cfg->N + 4 * resident) / (8 * resident);
-    if (EB < 1) EB = 1;
-    if (EB > cap) EB = cap;
-    const char *ov = getenv("FE_TILE_ENVS");
-    if (ov && atoi(ov) > 0) EB = atoi(ov) < cap ? atoi(ov) : cap;
-    const int64_t num_tiles = (cfg->N + EB - 1) / EB;
-    // the LDS footprint depends on EB: ask again with the real size before fixing the grid
-    he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel_for<false>(cfg->obs_is_f32 != 0, vec, A == 1),
-                                                      kBlock, lds_bytes((int)EB, A));
-    if (he == hipSuccess && per_cu >= 1) {
-        if (per_cu > 8) per_cu = 8;
-        resident = (int64_t)prop.multiProcessorCount * per_cu;
-        if (resident > 8) resident -= resident % 8;
-    }
-    int64_t grid = num_tiles < resident ? num_tiles : resident;
-    const char *gv = getenv("FE_GRID");
-    if (gv && atoi(gv) > 0) grid = atoi(gv);
-    env->grid = (int)grid;
-    env->lds = lds_bytes((int)EB, A);
-
+    env->cus = prop.multiProcessorCount;
+    env->tile_override = 0;
+    env->grid_override = 0;
+    env->rollout_tile_override = 0;
     Params &p = env->p;
     memset(&p, 0, sizeof(p));
+    p.N = cfg->N;
+    p.A = A;
+    if (int rc = configure_launch(env)) {
+        if (env->owned_logret) (void)hipFree(env->owned_logret);
+        delete env;
+        return rc;
+    }
     p.P = prices;
     p.LR = logret;
     p.N = cfg->N; p.D = cfg->D; p.L = cfg->L;
-    p.W = cfg->W; p.A = A; p.EB = (int)EB;
-    p.num_tiles = num_tiles;
+    p.W = cfg->W; p.A = A;
     p.eval_env = cfg->evaluate ? -1 : cfg->eval_env;
     p.seed = cfg->seed;
     p.evaluate = cfg->evaluate ? 1 : 0;
@@ -1331,6 +1437,8 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
 int fe_env_describe(fe_env *env, int64_t *obs_src, double *obs_pos, void *stream) {
     if (!env || !obs_src || !obs_pos) return fail(FE_ERR_ARG, "fe_env_describe: null argument");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_describe: state not bound");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     const Params &p = env->p;
     dim3 g(grid_for(p.N * p.A)), b(kBlock);
     if (p.A == 1)
@@ -1344,6 +1452,8 @@ int fe_env_describe(fe_env *env, int64_t *obs_src, double *obs_pos, void *stream
 
 int fe_env_render(fe_env *env, const int64_t *obs_src, const double *obs_pos, void *obs, void *stream) {
     if (!env || !obs_src || !obs_pos || !obs) return fail(FE_ERR_ARG, "fe_env_render: null argument");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     Params p = env->p;
     p.obs = obs;
     const bool f32 = env->cfg.obs_is_f32 != 0, single = p.A == 1;
@@ -1375,6 +1485,8 @@ int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32
     if (!env || !weights || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
         return fail(FE_ERR_ARG, "fe_env_rollout_linear: bad argument");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_linear: state not bound");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     Params p = env->p;
     // the rollout is latency-bound (policy -> accounting -> policy ...): 64 sleeves per workgroup measured
     // best at 64k envs (tools/fused_bench.py), independent of the tile the streaming step kernel uses
@@ -1382,8 +1494,7 @@ int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32
     int64_t eb = 64 / p.A;
     if (eb < 8) eb = 8;  // but never fewer than 8 envs per workgroup when they fit
     if (eb > cap) eb = cap;
-    const char *ov = getenv("FE_TILE_ENVS");
-    if (ov && atoi(ov) > 0) eb = atoi(ov) < cap ? atoi(ov) : cap;
+    if (env->rollout_tile_override > 0) eb = env->rollout_tile_override < cap ? env->rollout_tile_override : cap;
     p.EB = (int)eb;
     p.num_tiles = (p.N + eb - 1) / eb;
     const size_t lds = rollout_lds_bytes(p.EB, p.A, p.W);
@@ -1405,6 +1516,8 @@ int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32
 
 int fe_policy_table(fe_env *env, const double *weights, double *table, double *wsum, void *stream) {
     if (!env || !weights || !table || !wsum) return fail(FE_ERR_ARG, "fe_policy_table: null argument");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     const Params &p = env->p;
     const int64_t entries = p.D * p.L * p.A;
     int64_t blocks = (entries * 64 + kBlock - 1) / kBlock;
@@ -1423,11 +1536,12 @@ int fe_env_rollout_table(fe_env *env, const double *table, const double *wsum, d
     if (!env || !table || !wsum || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
         return fail(FE_ERR_ARG, "fe_env_rollout_table: bad argument");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_table: state not bound");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     Params p = env->p;
     // lane-private loop (no LDS traffic at one asset): full workgroups of sleeves
     int64_t eb = kBlock / p.A > 0 ? kBlock / p.A : 1;
-    const char *ov = getenv("FE_TILE_ENVS");
-    if (ov && atoi(ov) > 0 && atoi(ov) < eb) eb = atoi(ov);
+    if (env->rollout_tile_override > 0 && env->rollout_tile_override < eb) eb = env->rollout_tile_override;
     p.EB = (int)eb;
     p.num_tiles = (p.N + eb - 1) / eb;
     TableRolloutArgs r;
@@ -1449,6 +1563,8 @@ int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream) {
     if (!env || !env->bound) return fail(FE_ERR_STATE, "fe_env_set_day: env not bound");
     if (env_index < 0 || env_index >= env->cfg.N || day < 0 || day >= env->cfg.D)
         return fail(FE_ERR_ARG, "fe_env_set_day: env %lld / day %lld out of range", (long long)env_index, (long long)day);
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     hipError_t he = hipMemcpyAsync(env->p.env_idx + env_index, &day, sizeof(int64_t), hipMemcpyHostToDevice,
                                    (hipStream_t)stream);
     if (he != hipSuccess) return hip_fail(he, "fe_env_set_day");
@@ -1467,16 +1583,53 @@ int fe_env_launch_info(const fe_env *env, int32_t *grid, int32_t *block, int32_t
     return FE_OK;
 }
 
+int fe_env_set_launch(fe_env *env, int32_t tile_envs, int32_t grid, int32_t rollout_tile_envs) {
+    if (!env) return fail(FE_ERR_ARG, "fe_env_set_launch: null env");
+    if (tile_envs < 0 || grid < 0 || rollout_tile_envs < 0) return fail(FE_ERR_ARG, "fe_env_set_launch: negative value");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    env->tile_override = tile_envs;
+    env->grid_override = grid;
+    env->rollout_tile_override = rollout_tile_envs;
+    return configure_launch(env);
+}
+
+const char *fe_build_tag(void) { return FE_BUILD_TAG; }
+
 int fe_env_destroy(fe_env *env) {
+    if (env && env->owned_logret) {
+        DeviceGuard guard(env->device);
+        (void)hipFree(env->owned_logret);
+    }
     delete env;
     return FE_OK;
 }
 
+int fe_env_device(const fe_env *env) {
+    if (!env) return fail(FE_ERR_ARG, "fe_env_device: null env");
+    return env->device;
+}
+
+const double *fe_env_logret(const fe_env *env) { return env ? env->p.LR : nullptr; }
+
 int fe_build_logret(const double *prices, double *out, int64_t T, int32_t A, void *stream) {
     if (!prices || !out || T < 1 || A < 1) return fail(FE_ERR_ARG, "fe_build_logret: bad argument");
+    DeviceGuard guard(device_of(prices));
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     hipLaunchKernelGGL(fe_logret_kernel, dim3(grid_for(T * A)), dim3(kBlock), 0, (hipStream_t)stream, prices, out, T, A);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "fe_build_logret launch");
+    return FE_OK;
+}
+
+int fe_build_logret_tables(const double *prices, double *out, int64_t D, int64_t L, int32_t A, void *stream) {
+    if (!prices || !out || D < 1 || L < 1 || A < 1) return fail(FE_ERR_ARG, "fe_build_logret_tables: bad argument");
+    DeviceGuard guard(device_of(prices));
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    hipLaunchKernelGGL(fe_logret_tables_kernel, dim3(grid_for(D * L * A)), dim3(kBlock), 0, (hipStream_t)stream, prices,
+                       out, D, L, A);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_build_logret_tables launch");
     return FE_OK;
 }
 
@@ -1484,6 +1637,8 @@ int fe_build_tables(const double *series, const int64_t *starts, const int64_t *
                     int32_t A, double *out, void *stream) {
     if (!series || !starts || !stops || !out || D < 1 || L < 1 || A < 1)
         return fail(FE_ERR_ARG, "fe_build_tables: bad argument");
+    DeviceGuard guard(device_of(series));
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     hipLaunchKernelGGL(fe_tables_kernel, dim3(grid_for(D * L * 4 * A)), dim3(kBlock), 0, (hipStream_t)stream, series,
                        starts, stops, D, L, A, out);
     hipError_t he = hipGetLastError();
@@ -1496,6 +1651,8 @@ int fe_traj_store(int64_t t, int64_t N, int32_t A, const float *actions, const d
                   void *stream) {
     if (t < 0 || N < 1 || A < 1 || !actions || !rewards || !dones || !traj_actions || !traj_rewards || !traj_dones)
         return fail(FE_ERR_ARG, "fe_traj_store: bad argument");
+    DeviceGuard guard(device_of(traj_rewards));
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     const int64_t NA = N * A;
     hipLaunchKernelGGL(fe_traj_store_kernel, dim3(grid_for(NA)), dim3(kBlock), 0, (hipStream_t)stream, N, NA, actions,
                        rewards, dones, traj_actions + t * NA, traj_rewards + t * N, traj_dones + t * N);
@@ -1508,6 +1665,8 @@ int fe_traj_returns(const double *rewards, const int32_t *dones, const float *va
                     int64_t T, int64_t N, double gamma, float *returns, float *advantages, void *stream) {
     if (!rewards || !dones || !last_values || !returns || T < 1 || N < 1 || (advantages && !values))
         return fail(FE_ERR_ARG, "fe_traj_returns: bad argument");
+    DeviceGuard guard(device_of(rewards));
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     hipLaunchKernelGGL(fe_traj_returns_kernel, dim3(grid_for(N)), dim3(kBlock), 0, (hipStream_t)stream, rewards, dones,
                        values, last_values, T, N, (float)gamma, returns, advantages);
     hipError_t he = hipGetLastError();

@@ -62,7 +62,7 @@ class TimeSeriesEnv:
         day_id=None,
         tables=None,
         obs_dtype: torch.dtype = torch.float64,
-        obs_buffers: int = 2,
+        obs_buffers: int = 0,
         redraw: str = "torch",
         seed: int = 0,
         env_indices=None,
@@ -274,6 +274,12 @@ class TimeSeriesEnv:
         g, b, t, l = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
         _lib.check(self._lib.fe_env_launch_info(self._handle, C.byref(g), C.byref(b), C.byref(t), C.byref(l)))
         return {"grid": g.value, "block": b.value, "tile_envs": t.value, "lds_bytes": l.value}
+
+    def set_launch(self, tile_envs: int = 0, grid: int = 0, rollout_tile_envs: int = 0) -> Dict[str, int]:
+        """Tuning hook for tools/: override the tile (envs per workgroup) / grid of the step kernel and the
+        tile of the fused rollouts; 0 = automatic.  Returns the resulting launch_info()."""
+        _lib.check(self._lib.fe_env_set_launch(self._handle, int(tile_envs), int(grid), int(rollout_tile_envs)))
+        return self.launch_info()
 
     def __del__(self):
         h = getattr(self, "_handle", None)

@@ -15,7 +15,12 @@
  *  - return value 0 on success, negative on error; fe_last_error() returns a
  *    thread-local description of the last failure;
  *  - the library creates no threads and owns no tensors: tables, state and
- *    outputs are caller-owned and must outlive the calls that use them.
+ *    outputs are caller-owned and must outlive the calls that use them (one
+ *    exception: the log-return table fe_env_create computes when passed NULL);
+ *  - multi-GPU processes: an env runs on the device its tables live on.  Every
+ *    entry point makes that device current for the call and restores the
+ *    caller's device afterwards, so the reference's `device_id` constructor
+ *    argument (TSE:28, 45) works without the caller switching devices.
  *
  * There is deliberately NO CPU implementation behind this ABI: without a GPU
  * every compute entry point fails with FE_ERR_HIP.
@@ -29,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FE_ABI_VERSION 1
+#define FE_ABI_VERSION 2
 #define FE_MAX_ASSETS 256
 
 #define FE_OK 0
@@ -72,7 +77,15 @@ int fe_device_count(void);
  * Replaces TimeSeriesEnv.__init__'s device-side setup (TSE:245-269 minus tensor
  * allocation).  `prices` and `logret` are the (D, L, 4*A) f64 NaN-padded tables
  * price_environments / log_return_environments (TSE:215-216), asset a in
- * columns 4a..4a+3 = O,H,L,C.  `cfg` is a host pointer.
+ * columns 4a..4a+3 = O,H,L,C.  `cfg` is a host pointer.  The env is created on the
+ * device `prices` lives on (not the caller's current device).
+ * logret == NULL: the library computes the table from `prices` with the transform of
+ * generate_log_return_dataset (TSE:179-194) applied per day slice and owns it until
+ * fe_env_destroy (fe_env_logret returns it).  One entry per day differs from the table
+ * the reference builds from the whole series: the open-over-previous-close feature of a
+ * slice's row 0, whose previous close lies outside the slice, takes the rule the reference
+ * applies to the first row of a series (open over open, i.e. 0; TSE:188-190).  Callers that
+ * need the reference's value there pass the table built by fe_build_logret + fe_build_tables.
  */
 int fe_env_create(const fe_config *cfg, const double *prices, const double *logret, fe_env **out);
 
@@ -170,13 +183,35 @@ int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream);
 int fe_env_launch_info(const fe_env *env, int32_t *grid, int32_t *block, int32_t *tile_envs,
                        int32_t *lds_bytes);
 
+/*
+ * Tuning only (tools/, never needed for correctness): override the tile size (envs per workgroup
+ * tile) and grid of the step / reset kernels and the tile of the fused rollouts; 0 = automatic.
+ */
+int fe_env_set_launch(fe_env *env, int32_t tile_envs, int32_t grid, int32_t rollout_tile_envs);
+
+/* "" for the product build; experiment builds report their -D set (and are refused by the default loader). */
+const char *fe_build_tag(void);
+
 int fe_env_destroy(fe_env *env);
+
+/* HIP device index the env runs on (that of its price table). */
+int fe_env_device(const fe_env *env);
+
+/* The (D, L, 4*A) log-return table the env reads: the caller's, or the one fe_env_create computed. */
+const double *fe_env_logret(const fe_env *env);
 
 /*
  * Replaces generate_log_return_dataset (TSE:179-194): whole-series transform,
  * prices/out (T, 4*A) f64.
  */
 int fe_build_logret(const double *prices, double *out, int64_t T, int32_t A, void *stream);
+
+/*
+ * The same transform (TSE:179-194) applied to an already sliced, NaN-padded price table
+ * (D, L, 4*A) -> out (D, L, 4*A): what fe_env_create(logret = NULL) computes.  Row 0 of every day
+ * takes the series-row-0 rule for its open-over-previous-close entry (see fe_env_create).
+ */
+int fe_build_logret_tables(const double *prices, double *out, int64_t D, int64_t L, int32_t A, void *stream);
 
 /*
  * Replaces generate_environments (TSE:196-216): out[d][r] = series[starts[d]+r]

@@ -391,6 +391,42 @@ void fo_discounted_returns(const double *rew, const int32_t *done, const float *
 }
 
 /*
+ * The dtype rule every cash update of TSE:353-475 rests on: an in-place `f32 op= f64` computes in f64
+ * and rounds once on store.  Exposed on its own so that the known-answer probe of tests/golden/
+ * rounding.npz (e.g. 1f += 2^-24 + 2^-50 -> 1.00000012) pins it outside of any rollout.
+ */
+void fo_f32_iadd_f64(const float *base, const double *delta, int64_t n, int32_t subtract, float *out) {
+    for (int64_t i = 0; i < n; ++i)
+        out[i] = subtract ? (float)((double)base[i] - delta[i]) : (float)((double)base[i] + delta[i]);
+}
+
+/*
+ * f4: the agents' per-step return bookkeeping, finenvs/agents/PPO/PPO_agent.py:120-132 (the same
+ * lines exist in the TD3 / SAC agents): current_returns (f32) += rewards (f64); returns of finished
+ * TRAINING episodes (all envs but the last) are collected -- here as count / sum / sum of squares in
+ * f64 --; when the last env (the evaluation env) finishes, its return is recorded; finished envs'
+ * running returns restart at 0.  acc = {count, sum, sum of squares}, eval = {last return, how many}.
+ */
+void fo_episode_stats_step(int64_t N, int64_t eval_env, const double *rew, const int32_t *done, float *running,
+                           double *acc, float *eval) {
+    for (int64_t n = 0; n < N; ++n) {
+        float cr = (float)((double)running[n] + rew[n]);  /* PPO_agent.py:121 */
+        if (done[n]) {
+            if (n == eval_env) {                           /* PPO_agent.py:129-131 */
+                eval[0] = cr;
+                eval[1] += 1.0f;
+            } else {                                       /* PPO_agent.py:122-128, 132 */
+                acc[0] += 1.0;
+                acc[1] += (double)cr;
+                acc[2] += (double)cr * (double)cr;
+            }
+            cr = 0.0f;
+        }
+        running[n] = cr;
+    }
+}
+
+/*
  * f2: the in-kernel linear policy of fe_env_rollout_linear, restated on a materialised
  * observation (N, W, 5A) f64.  The summation order is part of the contract: 64 partial sums
  * (lane l takes rows l, l+64, ... in order, features 0..4 inside a row), then a butterfly over

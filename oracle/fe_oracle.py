@@ -102,6 +102,42 @@ def discounted_returns(rew: np.ndarray, done: np.ndarray, last_values: np.ndarra
     return out
 
 
+def f32_iadd_f64(base: np.ndarray, delta: np.ndarray, subtract: bool = False) -> np.ndarray:
+    base = np.ascontiguousarray(base, dtype=np.float32)
+    delta = np.ascontiguousarray(delta, dtype=np.float64)
+    out = np.empty_like(base)
+    lib().fo_f32_iadd_f64(_p(base), _p(delta), C.c_int64(base.shape[0]), C.c_int32(int(subtract)), _p(out))
+    return out
+
+
+class EpisodeStatsOracle:
+    """PPO_agent.py:120-132 / 146-163 on numpy state (count / sum / sum of squares instead of a list)."""
+
+    def __init__(self, num_envs: int, eval_env: int):
+        self.N, self.eval_env = int(num_envs), int(eval_env)
+        self.running = np.zeros(self.N, dtype=np.float32)
+        self.acc = np.zeros(3, dtype=np.float64)
+        self.eval = np.zeros(2, dtype=np.float32)
+
+    def step(self, rewards: np.ndarray, dones: np.ndarray) -> None:
+        rewards = np.ascontiguousarray(rewards, dtype=np.float64)
+        dones = np.ascontiguousarray(dones, dtype=np.int32)
+        lib().fo_episode_stats_step(C.c_int64(self.N), C.c_int64(self.eval_env), _p(rewards), _p(dones),
+                                    _p(self.running), _p(self.acc), _p(self.eval))
+
+    def read(self, reset: bool = True):
+        n, s, ss = (float(x) for x in self.acc)
+        mean = s / n if n > 0 else float("nan")
+        var = (ss - n * mean * mean) / (n - 1) if n > 1 else float("nan")
+        out = {"num_training_episodes": int(n), "mean_training_return": mean,
+               "std_dev_training_return": max(var, 0.0) ** 0.5 if n > 1 else float("nan"),
+               "evaluation_return": float(self.eval[0]) if self.eval[1] > 0 else None}
+        if reset:
+            self.acc[:] = 0
+            self.eval[:] = 0
+        return out
+
+
 def policy_linear(obs: np.ndarray, weights: np.ndarray, bias: float) -> np.ndarray:
     """Actions (N, A) f32 of the in-kernel linear policy on a materialised observation (N, W, 5A)."""
     obs = np.ascontiguousarray(obs, dtype=np.float64)

@@ -10,6 +10,7 @@ of the reference is written into this repository: only arrays (inputs we
 generated ourselves + the outputs the reference computed from them).
 
     python oracle/make_goldens.py            # rewrites tests/golden/*.npz
+    python oracle/make_goldens.py tables_ibm.npz rollout_spy_w4.npz   # only the named fixtures
 
 Inputs are the build's own seeded synthetic CSVs (finenvs_amd.data.synthetic),
 plus one real-data case: the reference's smallest test fixture
@@ -38,6 +39,21 @@ from finenvs_amd.data import synthetic  # noqa: E402
 REF = "/root/reference"
 WORK = "/tmp/fe_oracle_work"
 GOLD = os.path.join(REPO, "tests", "golden")
+ONLY = set(a for a in sys.argv[1:] if a.endswith(".npz"))  # empty = write everything
+
+
+def wanted(fname: str) -> bool:
+    return not ONLY or os.path.basename(fname) in ONLY
+
+
+def save_npz(path: str, **arrays) -> None:
+    """np.savez_compressed unless the fixture was filtered out on the command line (existing files stay
+    byte-identical when only new fixtures are added)."""
+    if wanted(path):
+        np.savez_compressed(path, **arrays)
+    else:
+        print("   (kept)", os.path.basename(path))
+
 
 
 def setup_reference():
@@ -119,7 +135,7 @@ def write_case_csv(name, num_days, bars, seed=1234, drop=0.0, premarket=2, asset
 
 def tables_case(fname, name, W, prices, day_id, minute):
     env, cache = make_env(name, W, evaluate=True)
-    np.savez_compressed(
+    save_npz(
         os.path.join(GOLD, fname),
         W=np.int64(W),
         series_prices=prices,
@@ -135,6 +151,41 @@ def tables_case(fname, name, W, prices, day_id, minute):
     )
     print(fname, tuple(env.price_environments.shape))
     return env
+
+
+def real_series_of(env):
+    """(day_id, minute, second) per market-hours row, from the reference's own filtered dataframe."""
+    df = env.dataframe
+    dates = df["Date"].values
+    uniq = {s_: i for i, s_ in enumerate(dict.fromkeys(dates))}
+    day_id = np.asarray([uniq[s_] for s_ in dates], dtype=np.int64)
+    hms = [[int(x) for x in str(t).strip().split(":")] + [0] for t in df["Time"].values]
+    second = np.asarray([h[0] * 3600 + h[1] * 60 + h[2] for h in hms], dtype=np.int64)
+    return day_id, second // 60, second
+
+
+def real_tables_case(inst, W, fname):
+    if not os.path.isdir(data_dir(inst)):
+        os.makedirs(data_dir(inst))
+        shutil.copy(os.path.join(REF, "finenvs", "data", inst, "dummy.csv"), os.path.join(data_dir(inst), "dummy.csv"))
+    env, cache = make_env(inst, W, evaluate=True)
+    day_id, minute, second = real_series_of(env)
+    save_npz(
+        os.path.join(GOLD, fname),
+        W=np.int64(W),
+        series_prices=env.dataset.numpy(),
+        series_day_id=day_id,
+        series_minute=minute,
+        series_second=second,
+        ref_dataset=env.dataset.numpy(),
+        ref_log_return_dataset=env.log_return_dataset.numpy(),
+        ref_start_indices=np.asarray(cache["start_indices"], dtype=np.int64),
+        ref_stop_indices=np.asarray(cache["stop_indices"], dtype=np.int64),
+        ref_max_length=np.int64(cache["max_length"]),
+        ref_price_environments=env.price_environments.numpy(),
+        ref_log_return_environments=env.log_return_environments.numpy(),
+    )
+    print(fname, tuple(env.price_environments.shape))
 
 
 def state_of(env):
@@ -209,9 +260,76 @@ def save_rollout(fname, env, roll, extra=None):
     meta.update(roll)
     if extra:
         meta.update(extra)
-    np.savez_compressed(os.path.join(GOLD, fname), **meta)
+    save_npz(os.path.join(GOLD, fname), **meta)
     nd = int(roll["dones"].sum())
     print(f"{fname}: steps={roll['dones'].shape[0]} N={env.num_envs} dones={nd}")
+
+
+def agent_stats_case():
+    """Runs the reference's own PPOAgent.store / log_progress (PPO_agent.py:110-168) -- without its networks --
+    on a reference training rollout and records what they compute: the running return per env after every
+    step, and at every log point the evaluation return, the number of finished training episodes and their
+    mean / std."""
+    import finenvs.agents.PPO.PPO_agent as agmod
+
+    class _NoBuffer:  # the trajectory half of store() is not what is pinned here
+        def __init__(self):
+            self.n = 0
+
+        def store(self, *a):
+            self.n += 1
+
+        def size(self):
+            return self.n
+
+    agent = object.__new__(agmod.PPOAgentMLP)
+    torch.manual_seed(99)
+    env, _ = make_env("SYN_stress", 8, starting_balance=800)
+    scale_env(env, 40)
+    N = env.num_envs
+    agent.num_envs = N
+    agent.device = "cpu"
+    agent.buffer = _NoBuffer()
+    agent.current_returns = torch.zeros((N,))
+    agent.training_returns = torch.zeros((0, 1))
+    agent.evaluation_return = None
+    agent.num_samples = 0
+    agent.num_steps = 0
+    agent.save_interval = 0
+    agent.write_to_csv = False
+    g = torch.Generator().manual_seed(17)
+    T, LOG_EVERY = 160, 20
+    rec = {k: [] for k in ("actions", "rewards", "dones", "env_idx", "running")}
+    logs = []
+    init = state_of(env)
+    env.reset()
+    for t in range(T):
+        a = (torch.rand((N, 1), generator=g) * 2 - 1).float()
+        obs, rew, done, _ = env.step(a)
+        agent.store(obs, a, rew, done, torch.zeros((N, 1)), torch.zeros((N, 1)))
+        rec["actions"].append(a.squeeze(1).numpy().copy())
+        rec["rewards"].append(rew.numpy().copy())
+        rec["dones"].append(done.numpy().copy())
+        rec["env_idx"].append(env.env_indices.numpy().copy())
+        rec["running"].append(agent.current_returns.numpy().copy())
+        if (t + 1) % LOG_EVERY == 0:
+            tr = agent.training_returns.clone()
+            ev = agent.evaluation_return
+            logged = agent.log_progress()
+            logs.append((t, -1.0 if ev is None else float(ev), float(ev is not None), float(tr.shape[0]),
+                         float(tr.mean().item()) if tr.numel() else float("nan"),
+                         float(tr.std().item()) if tr.numel() > 1 else float("nan"), float(bool(logged))))
+    save_npz(
+        os.path.join(GOLD, "agent_stats.npz"),
+        W=np.int64(8), N=np.int64(N), starting_balance=np.float64(800), torch_seed=np.int64(99),
+        prices=env.price_environments.numpy(), logret=env.log_return_environments.numpy(),
+        init_env_idx=init["env_idx"],
+        log_every=np.int64(LOG_EVERY),
+        # columns: step, evaluation_return, has_evaluation_return, num_training_episodes, mean, std, logged
+        logs=np.asarray(logs, dtype=np.float64),
+        **{k: np.stack(v) for k, v in rec.items()},
+    )
+    print("agent_stats.npz logs:", [(int(l[0]), int(l[3])) for l in logs])
 
 
 def main():
@@ -225,30 +343,11 @@ def main():
     tables_case("tables_ragged.npz", "SYN_ragged", 8, p, d, m)
     p, d, m = write_case_csv("SYN_skip2", 6, 40, seed=5)
     tables_case("tables_skip2.npz", "SYN_skip2", 50, p, d, m)
-    # real data: the reference's smallest fixture; store its market-hours rows as arrays
-    os.makedirs(data_dir("OIH"))
-    shutil.copy(os.path.join(REF, "finenvs", "data", "OIH", "dummy.csv"), os.path.join(data_dir("OIH"), "dummy.csv"))
-    env, cache = make_env("OIH", 32, evaluate=True)
-    df = env.dataframe
-    dates = df["Date"].values
-    uniq = {s: i for i, s in enumerate(dict.fromkeys(dates))}
-    day_id = np.asarray([uniq[s] for s in dates], dtype=np.int64)
-    minute = np.asarray([int(t[:2]) * 60 + int(t[3:5]) for t in df["Time"].values], dtype=np.int64)
-    np.savez_compressed(
-        os.path.join(GOLD, "tables_oih.npz"),
-        W=np.int64(32),
-        series_prices=env.dataset.numpy(),
-        series_day_id=day_id,
-        series_minute=minute,
-        ref_dataset=env.dataset.numpy(),
-        ref_log_return_dataset=env.log_return_dataset.numpy(),
-        ref_start_indices=np.asarray(cache["start_indices"], dtype=np.int64),
-        ref_stop_indices=np.asarray(cache["stop_indices"], dtype=np.int64),
-        ref_max_length=np.int64(cache["max_length"]),
-        ref_price_environments=env.price_environments.numpy(),
-        ref_log_return_environments=env.log_return_environments.numpy(),
-    )
-    print("tables_oih.npz", tuple(env.price_environments.shape))
+    # real data: the reference's own three fixtures (tests/unit/test_time_series_env.py:10-14); the
+    # market-hours rows the reference's pandas parse kept are stored as plain arrays
+    for inst, W, fname in (("OIH", 32, "tables_oih.npz"), ("IBM", 390, "tables_ibm.npz"), ("SPY", 390, "tables_spy.npz"),
+                           ("IBM", 4, "tables_ibm_w4.npz"), ("SPY", 4, "tables_spy_w4.npz")):
+        real_tables_case(inst, W, fname)
 
     # ---------------- rollouts (a2-a17) ----------------
     write_case_csv("SYN_roll", 7, 40, seed=1234)
@@ -299,6 +398,19 @@ def main():
     roll = rollout(env, 700, full_obs=False)
     save_rollout("rollout_oih.npz", env, roll, {"torch_seed": np.int64(2024)})
 
+    # the reference's other two fixtures, at the default window (TSE:19) and at the example's
+    # (examples/time_series/PPO_LSTM_training_SPY.py:8); native training mode (N = D + 1, eval env redraws)
+    for inst, W, T, seed in (("IBM", 390, 900, 11), ("SPY", 390, 900, 12), ("IBM", 4, 900, 13), ("SPY", 4, 900, 14)):
+        fname = f"rollout_{inst.lower()}_w{W}.npz"
+        if not wanted(fname):
+            print("   (kept)", fname)
+            continue
+        torch.manual_seed(seed)
+        env, _ = make_env(inst, W)
+        roll = rollout(env, T, action_seed=100 + seed, full_obs=False)
+        roll["obs_reset"] = roll["obs_reset"][:, -1, :]  # last row only (W=390 windows are large)
+        save_rollout(fname, env, roll, {"torch_seed": np.int64(seed), "obs_reset_last_row_only": np.int64(1)})
+
     # edge-case actions: NaN, +-inf, out-of-range, -0.0 (a diverged policy must not crash or desync parity)
     env, _ = make_env("SYN_roll", 8, evaluate=True, starting_balance=3000)
     scale_env(env, 24)
@@ -335,7 +447,7 @@ def main():
         obss.append(torch.cat(o_l, dim=2).numpy().copy())
         for k2 in st:
             st[k2].append(np.stack([state_of(e)[k2] for e in envs], axis=1))
-    np.savez_compressed(
+    save_npz(
         os.path.join(GOLD, "rollout_sleeves3.npz"),
         W=np.int64(8), N=np.int64(N), A=np.int64(A), evaluate=np.int64(1),
         max_shares=np.int64(5), starting_balance=np.float64(10000), commission=np.float64(0.01),
@@ -359,7 +471,21 @@ def main():
     sc = env.get_share_changes_from_actions(torch.from_numpy(probes).unsqueeze(1)).squeeze(1).numpy()
     env9, _ = make_env("SYN_roll", 8, evaluate=True, max_shares=9)
     sc9 = env9.get_share_changes_from_actions(torch.from_numpy(probes).unsqueeze(1)).squeeze(1).numpy()
-    np.savez_compressed(os.path.join(GOLD, "rounding.npz"), actions=probes, share_changes_ms5=sc, share_changes_ms9=sc9)
+    # f32 (op)= f64 in place: computed in f64, rounded ONCE on store (the dtype rule every cash update of
+    # TSE:353-475 relies on), e.g. 1f += 2^-24 + 2^-50 -> 1.00000012 (ties would give 1.0)
+    rng = np.random.default_rng(5)
+    base = np.concatenate([np.asarray([1.0, 1.0, 1.0, 10000.0, 9999.9990234375, 16777216.0, -0.0, 1e-38], dtype=np.float32),
+                           rng.uniform(-2e4, 2e4, 56).astype(np.float32)])
+    delta = np.concatenate([np.asarray([2.0 ** -24 + 2.0 ** -50, 2.0 ** -24, 2.0 ** -24 - 2.0 ** -60, 0.00048828125 + 1e-13,
+                                        0.0009765625 / 2, 1.0 + 2.0 ** -30, 0.0, 1e-46], dtype=np.float64),
+                            rng.uniform(-700, 700, 56) * (1 + rng.uniform(-1e-9, 1e-9, 56))])
+    x = torch.from_numpy(base.copy())
+    x += torch.from_numpy(delta)  # f32 += f64
+    y = torch.from_numpy(base.copy())
+    y -= torch.from_numpy(delta)  # f32 -= f64
+    assert x.dtype == torch.float32 and float(x[0]) == float(np.float32(1.00000012))
+    save_npz(os.path.join(GOLD, "rounding.npz"), actions=probes, share_changes_ms5=sc, share_changes_ms9=sc9,
+             f32_base=base, f64_delta=delta, f32_iadd_f64=x.numpy(), f32_isub_f64=y.numpy())
     print("rounding.npz", sc.tolist())
 
     # ---------------- f1: PPO buffer discounted returns (buffer.py:80-100) ----------------
@@ -378,7 +504,7 @@ def main():
         buf.store(torch.zeros((N, 2, 5), dtype=torch.float64), torch.zeros((N, 1)), rew[t], done[t],
                   torch.zeros((N, 1)), val[t])
     buf.compute_returns_and_advantages(last)
-    np.savez_compressed(
+    save_npz(
         os.path.join(GOLD, "ppo_returns.npz"),
         gamma=np.float64(0.99), rewards=rew.numpy(), dones=done.numpy(), values=val.squeeze(-1).numpy(),
         last_values=last.squeeze(-1).numpy(),
@@ -386,6 +512,10 @@ def main():
         advantages=buf.container["advantages"].squeeze(-1).numpy().T.copy(),  # (T, N)
     )
     print("ppo_returns.npz", buf.container["returns"].dtype, buf.container["advantages"].dtype)
+
+    # ---------------- f4: the agents' return bookkeeping (PPO_agent.py:110-168) ----------------
+    if wanted("agent_stats.npz"):
+        agent_stats_case()
 
     # the reference tree must be untouched
     dirty = [p for p in glob.glob(os.path.join(REF, "finenvs", "data", "*", "*.json"))]

@@ -1,0 +1,195 @@
+"""GPU tests of the drop-in boundary's ownership and device rules (round-2 additions):
+
+* the default env returns FRESH observation tensors, so the reference's PPO buffer -- which keeps a
+  VIEW of the first stored `states` until its next torch.cat (finenvs/agents/PPO/buffer.py:45, 53-56)
+  -- stores the right states;
+* an env whose device_id is not the current device launches on its own device (TSE:28, 45);
+* fe_env_create(logret = NULL) computes the log-return table on the device.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    import finenvs_amd
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return finenvs_amd
+
+
+@pytest.fixture(scope="module")
+def fo():
+    from oracle import fe_oracle
+
+    fe_oracle.build()
+    return fe_oracle
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def _tables(fo, num_days, A, bars, W, seed=1234, drop=0.0):
+    from finenvs_amd.data import synthetic
+
+    prices, day_id, _ = synthetic.synthetic_series(num_days, A, bars, seed, drop)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    return P, LR
+
+
+class _RefBufferStates:
+    """The `states` half of the reference's PPO Buffer, restated (buffer.py:33-56): the first store keeps
+    `states.unsqueeze(1)` -- a VIEW of the caller's tensor -- and only the next store copies it (torch.cat)."""
+
+    def __init__(self):
+        self.container = None
+
+    def store(self, states: torch.Tensor) -> None:
+        t = states.unsqueeze(1)
+        self.container = t if self.container is None else torch.cat([self.container, t], dim=1)
+
+    def clear(self) -> None:
+        self.container = None
+
+
+@pytest.mark.parametrize("obs_buffers", [0, 3])
+def test_reference_buffer_retention_pattern(fe, fo, obs_buffers):
+    """reset -> [agent.step; env.step; agent.store(states, ...); states = next_states] x T, then clear, twice
+    (examples/time_series/PPO_LSTM_training_SPY.py:22-30).  Every stored state must equal the oracle's
+    observation of that step.  obs_buffers=0 (the default) is the reference's fresh-tensor semantics; a ring
+    is safe for this loop only from 3 buffers up (with 2 the first state of every batch is overwritten before
+    the buffer's first torch.cat copies it -- the reason the ring is opt-in)."""
+    P, LR = _tables(fo, 6, 1, 40, 8)
+    N, W, T = 33, 8, 5
+    ref = fo.OracleEnv(P, LR, W, num_envs=N, evaluate=True)
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_buffers=obs_buffers)
+    assert fe.TimeSeriesEnv.__init__.__kwdefaults__["obs_buffers"] == 0
+    buf = _RefBufferStates()
+    g = torch.Generator().manual_seed(4)
+    states = env.reset()
+    want = [ref.reset().copy()]
+    for batch in range(2):
+        for t in range(T):
+            a = (torch.rand((N, 1), generator=g) * 2 - 1).float()
+            next_states, _, _, _ = env.step(a.to(env.device))
+            ref.step(a.numpy())
+            want.append(ref.obs.copy())
+            buf.store(states)
+            states = next_states
+        stored = t2n(buf.container)  # (N, T, W, 5)
+        for t in range(T):
+            assert_bits(stored[:, t], want[batch * T + t], f"batch {batch}: stored state {t}")
+        buf.clear()
+
+
+def test_two_buffer_ring_would_corrupt_the_first_stored_state(fe, fo):
+    """Documents WHY the ring is opt-in: with obs_buffers=2 the buffer's view of state 0 is overwritten by step 2."""
+    P, LR = _tables(fo, 6, 1, 40, 8)
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=8, num_envs=9, evaluate=True, obs_buffers=2)
+    buf = _RefBufferStates()
+    a = torch.full((9, 1), 0.7, device=env.device)
+    s0 = env.reset()
+    keep0 = s0.clone()
+    s1, *_ = env.step(a)
+    buf.store(s0)          # a view of ring buffer 0
+    s2, *_ = env.step(a)   # writes ring buffer 0 again
+    buf.store(s1)
+    assert s2.data_ptr() == s0.data_ptr()
+    assert not torch.equal(buf.container[:, 0], keep0)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two visible GPUs")
+def test_env_on_a_device_that_is_not_current(fe, fo):
+    """device_id=1 while cuda:0 is current: construction, reset, step, rollouts and the trajectory kernels all run
+    on cuda:1 and equal the same env built on cuda:0; the caller's current device is left alone."""
+    from finenvs_amd.rollout import FusedLinearRollout
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    P, LR = _tables(fo, 6, 2, 40, 8)
+    N, A, W, T = 300, 2, 8, 12
+    torch.cuda.set_device(0)
+    envs = [fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, redraw="device", seed=3, device_id=d)
+            for d in (0, 1)]
+    assert envs[1].device == "cuda:1" and envs[1]._lib.fe_env_device(envs[1]._handle) == 1
+    assert torch.cuda.current_device() == 0
+    trajs = [TrajectoryBuffer(T, N, A, device=e.device) for e in envs]
+    g = torch.Generator().manual_seed(8)
+    o = [e.reset() for e in envs]
+    assert torch.equal(o[0].cpu(), o[1].cpu())
+    for t in range(T):
+        a = (torch.rand((N, A), generator=g) * 2 - 1).float()
+        outs = []
+        for e, tr in zip(envs, trajs):
+            sa, sr, sd = tr.next_slot()
+            sa.copy_(a.to(e.device))
+            outs.append(e.step(sa, rewards_out=sr, dones_out=sd))
+        assert outs[1][0].device == torch.device("cuda:1")
+        for x, y in zip(outs[0][:3], outs[1][:3]):
+            assert torch.equal(x.cpu(), y.cpu()), f"step {t}"
+        assert torch.cuda.current_device() == 0
+    vals = torch.zeros((T, N))
+    r0 = trajs[0].returns_and_advantages(vals.to("cuda:0"), torch.zeros(N, device="cuda:0"))
+    r1 = trajs[1].returns_and_advantages(vals.to("cuda:1"), torch.zeros(N, device="cuda:1"))
+    assert torch.equal(r0[0].cpu(), r1[0].cpu())
+    w = torch.randn((W, 5), dtype=torch.float64, generator=torch.Generator().manual_seed(1))
+    rolls = [FusedLinearRollout(e, w, 0.1) for e in envs]
+    res = [r.run(6) for r in rolls]
+    for x, y in zip(res[0], res[1]):
+        assert torch.equal(x.cpu(), y.cpu())
+    assert torch.cuda.current_device() == 0
+
+
+def test_fe_env_create_computes_the_log_return_table_when_passed_null(fe, fo):
+    """`logret = NULL -> computed`.  Equal to the table built from the whole series (a18) except the
+    open-over-previous-close entry of each day's row 0, whose previous close lies outside the slice (documented
+    in include/finenvs_amd.h): there the library applies the series-row-0 rule, 100*ln(O/O) = 0."""
+    from finenvs_amd import _lib
+
+    lib = _lib.load()
+    A, W, N = 2, 8, 50
+    P, LR = _tables(fo, 6, A, 40, W, drop=0.1)
+    D, L, _ = P.shape
+    dP = torch.from_numpy(P).cuda()
+    cfg = _lib.FeConfig(N, D, L, W, A, 5, 0, 1e4, 0.01, 1.5, 0.25, 0, 0, 0, -1)  # training mode, no eval env
+    h = C.c_void_p()
+    _lib.check(lib.fe_env_create(C.byref(cfg), dP.data_ptr(), None, C.byref(h)))
+    assert lib.fe_env_logret(h) not in (None, 0, dP.data_ptr())
+    got = torch.empty((D, L, 4 * A), dtype=torch.float64, device="cuda")
+    _lib.check(lib.fe_build_logret_tables(dP.data_ptr(), got.data_ptr(), D, L, A, None))  # the same kernel, caller-owned output
+    torch.cuda.synchronize()
+    got = t2n(got)
+    want = LR.copy()
+    first_open = np.zeros_like(want, dtype=bool)
+    first_open[:, 0, 0::4] = True
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got[~first_open], want[~first_open], rtol=1e-13, atol=1e-17)
+    assert np.all(got[first_open] == 0.0)
+    # and the env built on it steps like the oracle fed the same table
+    idx = torch.arange(N, dtype=torch.int64, device="cuda") % D
+    z = lambda dt, n=N * A: torch.zeros((n,), dtype=dt, device="cuda")  # noqa: E731
+    spot, cash, lng, sht, mar = z(torch.int64, N), torch.full((N * A,), 1e4, device="cuda"), z(torch.float32), z(torch.float32), z(torch.float64)
+    ctr = z(torch.int64, 2)
+    _lib.check(lib.fe_env_bind_state(h, idx.data_ptr(), spot.data_ptr(), cash.data_ptr(), lng.data_ptr(), sht.data_ptr(),
+                                     mar.data_ptr(), None, None, ctr.data_ptr()))
+    ref = fo.OracleEnv(P, got, W, num_envs=N, evaluate=False, eval_env=-1)
+    obs = torch.empty((N, W, 5 * A), dtype=torch.float64, device="cuda")
+    rew, done = z(torch.float64, N), z(torch.int32, N)
+    g = torch.Generator().manual_seed(6)
+    for t in range(60):
+        a = (torch.rand((N, A), generator=g) * 2 - 1).float()
+        da = a.cuda()
+        _lib.check(lib.fe_env_step(h, da.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), None))
+        torch.cuda.synchronize()
+        o_r, r_r, d_r, _ = ref.step(a.numpy())
+        assert_bits(t2n(obs), o_r, f"step {t} obs")
+        assert_bits(t2n(rew), r_r, f"step {t} rewards")
+        assert_bits(t2n(done), d_r, f"step {t} dones")
+    assert lib.fe_env_destroy(h) == 0

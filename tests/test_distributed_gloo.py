@@ -1,10 +1,11 @@
-"""World-size-2 rehearsal of the multi-GPU path on CPU (gloo): contiguous env shards, eval env on the
+"""World-size-2 and -8 rehearsals of the multi-GPU path on CPU (gloo): contiguous env shards, eval env on the
 last rank, one packed all-gather of the compact trajectory fields per chunk.  (On MI355X the same code
 runs with backend "nccl" = RCCL; bench.py --gpus N exercises it.)"""
 import os
 import socket
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -12,10 +13,10 @@ import torch.multiprocessing as mp
 from finenvs_amd.environments.time_series_env import shard_range
 from finenvs_amd.trajectory import TrajectoryBuffer
 
-T, N_TOTAL, A = 5, 15, 3  # 15 envs over 2 ranks: shards of 8 and 7 (capacity 8)
-
-
-CAP = (N_TOTAL + 1) // 2
+T, A = 5, 3
+# (world, total envs): 15 envs over 2 ranks -> shards of 8 and 7 (capacity 8); 27 envs over 8 ranks -> three
+# shards of 4 and five of 3 (capacity 4), N not divisible by the world size, eval env on rank 7
+CASES = [(2, 15), (8, 27)]
 
 
 def _free_port():
@@ -34,7 +35,8 @@ def _fill(buf, lo, n):
         buf.store(actions, rewards, dones)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, N_TOTAL):
+    CAP = (N_TOTAL + world - 1) // world
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -70,6 +72,7 @@ def _worker(rank, world, port, q):
         buf.all_gather_async()
         a3, r3, d3 = buf.wait_gathered()
         ok &= float(r3[rank][0, 0]) == (lo + 1000) * 0.5
+        ok &= tuple(a3.shape) == (world, T, CAP, A)
         buf.drain()
         # the eval env (last global env) is owned by the last rank only
         owns_eval = hi == N_TOTAL
@@ -83,19 +86,19 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_trajectory_all_gather_gloo():
-    world = 2
+@pytest.mark.parametrize("world,n_total", CASES)
+def test_trajectory_all_gather_gloo(world, n_total):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, n_total)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(180)
         assert p.exitcode == 0
     got = sorted(q.get(timeout=5) for _ in range(world))
-    assert got == [(0, True), (1, True)]
+    assert got == [(r, True) for r in range(world)]
 
 
 def test_shards_cover_days_like_the_single_process_env():

@@ -7,7 +7,9 @@ import torch
 from oracle import fe_oracle as fo
 from tests.helpers import assert_bits, econ_kwargs, load_golden
 
-TABLE_CASES = ["tables_full.npz", "tables_ragged.npz", "tables_skip2.npz", "tables_oih.npz"]
+TABLE_CASES = ["tables_full.npz", "tables_ragged.npz", "tables_skip2.npz", "tables_oih.npz",
+               # the reference's other two fixtures, at its default window (TSE:19) and the example's (W = 4)
+               "tables_ibm.npz", "tables_spy.npz", "tables_ibm_w4.npz", "tables_spy_w4.npz"]
 
 
 @pytest.mark.parametrize("name", TABLE_CASES)
@@ -47,7 +49,10 @@ def _replay(g, name, host_redraw=False, check_obs_full=True):
         first = int(torch.randint(0, D, (1,)))  # the constructor's draw, TSE:253-255
         if N == D + 1:  # the replicated fixtures overwrite env_indices after construction
             assert first == int(g["init_env_idx"][-1])
-    assert_bits(env.reset(), g["obs_reset"].reshape(N, W, -1), f"{name} reset obs")
+    if int(g.get("obs_reset_last_row_only", 0)):
+        assert_bits(env.reset()[:, -1, :], g["obs_reset"], f"{name} reset obs (last row)")
+    else:
+        assert_bits(env.reset(), g["obs_reset"].reshape(N, W, -1), f"{name} reset obs")
     T = g["actions"].shape[0]
     returns = None
     for t in range(T):
@@ -117,6 +122,16 @@ def test_real_data_oih_rollout():
     _replay(g, "rollout_oih", host_redraw=True, check_obs_full=False)
 
 
+@pytest.mark.parametrize("name", ["rollout_ibm_w390.npz", "rollout_spy_w390.npz", "rollout_ibm_w4.npz", "rollout_spy_w4.npz"])
+def test_real_data_ibm_spy_rollouts(name):
+    """The reference's own unit test builds IBM, OIH and SPY (tests/unit/test_time_series_env.py:10-14) and steps
+    them 1000 times; these are 900-step training rollouts of the reference on IBM and SPY, at its default window
+    (W = 390, TSE:19) and at the example's (W = 4), eval-env redraws included."""
+    g = load_golden(name)
+    assert g["dones"].sum() >= 4
+    _replay(g, name, host_redraw=True, check_obs_full=False)
+
+
 def test_multi_asset_sleeves_equal_side_by_side_references():
     g = load_golden("rollout_sleeves3.npz")
     W, N, A = int(g["W"]), int(g["N"]), int(g["A"])
@@ -150,6 +165,42 @@ def test_share_change_rounding_probes():
         got = env.long.reshape(-1) - env.short.reshape(-1)
         want = g[key]
         assert np.array_equal(got, want + 0.0)
+
+
+def test_f32_inplace_add_of_f64_rounds_once():
+    """SURVEY 8(c) `rounding_*`: the `f32 += f64` single-rounding probe, as a known-answer vector from torch."""
+    g = load_golden("rounding.npz")
+    assert_bits(fo.f32_iadd_f64(g["f32_base"], g["f64_delta"]), g["f32_iadd_f64"], "f32 += f64")
+    assert_bits(fo.f32_iadd_f64(g["f32_base"], g["f64_delta"], subtract=True), g["f32_isub_f64"], "f32 -= f64")
+    assert g["f32_iadd_f64"][0] == np.float32(1.00000012) and g["f32_iadd_f64"][1] == np.float32(1.0)
+    # double rounding (f64 sum -> f32 delta first) would get some of these wrong: the probe must be able to tell
+    naive = (g["f32_base"] + g["f64_delta"].astype(np.float32)).astype(np.float32)
+    assert (naive != g["f32_iadd_f64"]).any()
+
+
+def test_agent_return_bookkeeping_matches_reference_agent():
+    """agent_stats.npz was recorded from the reference's own PPOAgent.store / log_progress (PPO_agent.py:110-168)
+    during a reference training rollout: running returns bit-exact after every step; at every log point the same
+    evaluation return and episode count, mean / std of the finished-episode returns to f32 rounding (the
+    reference reduces an f32 list, the restatement keeps f64 sums)."""
+    g = load_golden("agent_stats.npz")
+    N = int(g["N"])
+    st = fo.EpisodeStatsOracle(N, N - 1)
+    logs = {int(r[0]): r for r in g["logs"]}
+    for t in range(g["rewards"].shape[0]):
+        st.step(g["rewards"][t], g["dones"][t])
+        assert_bits(st.running, g["running"][t], f"running returns after step {t}")
+        if t in logs:
+            _, ev, has_ev, n, mean, std, logged = logs[t]
+            got = st.read(reset=False)
+            assert (got["evaluation_return"] is not None) == bool(has_ev) == bool(logged)
+            assert got["num_training_episodes"] == int(n)
+            if has_ev:  # log_progress only reports (and clears) once an evaluation episode has finished
+                assert np.float32(got["evaluation_return"]) == np.float32(ev)
+                assert got["mean_training_return"] == pytest.approx(mean, rel=2e-6)
+                assert got["std_dev_training_return"] == pytest.approx(std, rel=2e-6)
+                st.read(reset=True)
+    assert sum(int(r[6]) for r in g["logs"]) >= 3
 
 
 def test_ppo_discounted_returns_match_reference_buffer():

@@ -8,7 +8,7 @@ def newest(pattern):
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, cfg = sys.argv[1], int(sys.argv[2])
-src = os.path.join(REPO, "gpurun_out", f"prof_{tag}_c{cfg}")
+src = os.path.join(REPO, "gpurun_out", f"prof_{tag}_c{cfg}" + ("_f32" if os.environ.get("PROF_F32") == "1" else ""))
 dst = os.path.join(REPO, "profiles")
 os.makedirs(dst, exist_ok=True)
 
@@ -17,7 +17,9 @@ def short(name):
     return name if len(name) < 110 else name[:107] + "..."
 
 stats = list(csv.DictReader(open(newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv")))))
-with open(os.path.join(dst, f"{tag}_c{cfg}_kernel_stats.csv"), "w", newline="") as f:
+F32 = "_f32" if os.environ.get("PROF_F32") == "1" else ""
+src_note = None
+with open(os.path.join(dst, f"{tag}_c{cfg}{F32}_kernel_stats.csv"), "w", newline="") as f:
     w = csv.writer(f)
     w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
     for r in stats:
@@ -40,7 +42,7 @@ bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().sp
 traffic = (2.0 * fetch_kb + write_kb) * 1024.0
 tj_path = os.path.join(dst, "hbm_traffic.json")
 tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
-tj[f"config{cfg}"] = {
+tj[f"config{cfg}" + ("_f32" if bench["dtype"] == "f32" else "")] = {
     "workload": bench["config"]["workload"], "tag": tag,
     "kernel": short(step["Name"]),
     "fetch_size_kib_raw_per_launch": fetch_kb, "write_size_kib_per_launch": write_kb,
@@ -53,14 +55,16 @@ tj[f"config{cfg}"] = {
 }
 json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
 r = bench["roofline"]
-N, B = r["units_per_launch"], r["algorithmic_bytes_per_env_step"]
+N, Bh, Bs = r["units_per_launch"], r["hbm_bytes_per_env_step"], r["survey_8d_bytes_per_env_step"]
 avg = float(step["AverageNs"])
-with open(os.path.join(dst, f"{tag}_c{cfg}_summary.md"), "w") as f:
-    f.write(f"# {tag} config {cfg}: {bench['config']['workload']}\n\n")
-    f.write(f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config {cfg} --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu` (+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)\n\n")
+key = f"{tag}_c{cfg}" + ("_f32" if bench["dtype"] == "f32" else "")
+with open(os.path.join(dst, f"{key}_summary.md"), "w") as f:
+    f.write(f"# {tag} config {cfg}: {bench['config']['workload']} ({bench['dtype']} observations)\n\n")
+    f.write(f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config {cfg} --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu --no-extra{' --obs-f32' if bench['dtype'] == 'f32' else ''}` (+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)\n\n")
     f.write(f"* step kernel `{short(step['Name'])}`: {step['Calls']} calls, avg {avg/1e3:.2f} us, min {float(step['MinNs'])/1e3:.2f} us, max {float(step['MaxNs'])/1e3:.2f} us ({step['Percentage']} % of GPU time)\n")
-    f.write(f"* bench.py under the profiler: {bench['value']:.4g} env-steps/s, {bench['ms_per_step']*1e3:.2f} us/step wall, HIP-event average launch interval {r['kernel_ms']*1e3:.2f} us (kernel + launch boundary, tight C-ABI loop)\n")
-    f.write(f"* algorithmic bytes per launch: {B} B x {N} envs = {B*N/1e6:.1f} MB -> {B*N/avg:.0f} GB/s at the rocprof average = {B*N/avg/8000*100:.1f} % of 8 TB/s\n")
-    f.write(f"* PMC (per launch): FETCH_SIZE {fetch_kb:.1f} KiB raw, WRITE_SIZE {write_kb:.1f} KiB -> HBM traffic ~ {traffic/1e6:.1f} MB ({traffic/avg:.0f} GB/s at the rocprof average)\n")
+    f.write(f"* bench.py under the profiler: {bench['value']:.4g} env-steps/s, {bench['ms_per_step']*1e3:.2f} us/step wall (median of {bench['repeats']['single_gpu']['blocks']} blocks), HIP-event average launch interval {r['kernel_ms']*1e3:.2f} us (kernel + launch boundary, tight C-ABI loop)\n")
+    f.write(f"* HBM bytes that must move per launch (observation write + state + outputs): {Bh} B x {N} envs = {Bh*N/1e6:.1f} MB -> {Bh*N/avg:.0f} GB/s at the rocprof average = **{Bh*N/avg/8000*100:.1f} % of 8 TB/s** (this is bench.py's `roofline.achieved` / `frac`)\n")
+    f.write(f"* PMC (per launch): FETCH_SIZE {fetch_kb:.1f} KiB raw, WRITE_SIZE {write_kb:.1f} KiB -> HBM traffic ~ {traffic/1e6:.1f} MB ({traffic/avg:.0f} GB/s at the rocprof average); traffic / compulsory bytes = {traffic/(Bh*N):.3f}\n")
+    f.write(f"* SURVEY 8(d) formula incl. the L2-served window re-read: {Bs} B per env-step = {Bs*N/1e6:.1f} MB per launch; the {r['l2_read_bytes_per_env_step']} B window part is L2 / Infinity-Cache traffic ({r['l2_read_bytes_per_env_step']*N/avg:.0f} GB/s), not HBM\n")
     f.write(f"* grid {meta.get('Grid_Size')} threads of 256 ({bench['config']['launch']})\n")
-print(open(os.path.join(dst, f"{tag}_c{cfg}_summary.md")).read())
+print(open(os.path.join(dst, f"{key}_summary.md")).read())
