@@ -91,6 +91,46 @@ inline int64_t parse_time(const char *b, const char *e) {
     return part[0] * 3600 + part[1] * 60 + part[2];
 }
 
+// Calendar dates in the spellings the reference's fixtures use (YYYY-MM-DD, MM/DD/YYYY; also with the
+// other separator) -> yyyymmdd; -1 for anything else (the date then stays an opaque text key).
+inline int64_t parse_date(const char *b, const char *e) {
+    int64_t part[3] = {0, 0, 0};
+    int len[3] = {0, 0, 0};
+    int k = 0;
+    char sep = 0;
+    for (const char *p = b; p < e; ++p) {
+        if (*p >= '0' && *p <= '9') {
+            if (++len[k] > 4) return -1;
+            part[k] = part[k] * 10 + (*p - '0');
+        } else if ((*p == '-' || *p == '/') && k < 2 && len[k] > 0 && (sep == 0 || sep == *p)) {
+            sep = *p;
+            ++k;
+        } else {
+            return -1;
+        }
+    }
+    if (k != 2 || len[2] == 0) return -1;
+    int64_t y, mth, d;
+    if (len[0] == 4 && len[1] <= 2 && len[2] <= 2) {  // year first
+        y = part[0]; mth = part[1]; d = part[2];
+    } else if (len[2] == 4 && len[0] <= 2 && len[1] <= 2) {  // month/day/year, the US spelling of IBM / OIH
+        mth = part[0]; d = part[1]; y = part[2];
+    } else {
+        return -1;
+    }
+    if (mth < 1 || mth > 12 || d < 1 || d > 31) return -1;
+    return y * 10000 + mth * 100 + d;
+}
+
+// 45-bit join key of a row's date: the calendar date where the text is one (so "2022-04-01" in one file
+// joins "04/01/2022" in another), else bit 44 + 44 bits of the text's FNV-1a hash.  Together with the
+// 17-bit second of day it fits an int64 without wrapping.
+inline int64_t date_join_key(const char *b, const char *e) {
+    const int64_t cal = parse_date(b, e);
+    if (cal >= 0) return cal;
+    return (int64_t)((fnv1a(b, e) >> 20) | (1ull << 44));
+}
+
 constexpr int64_t kOpen = (9 * 60 + 30) * 60;   // 09:30:00, first bar kept
 constexpr int64_t kLast = (15 * 60 + 59) * 60;  // 15:59:00, last bar kept (between_time is inclusive)
 
@@ -156,7 +196,7 @@ int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_onl
                 return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld: bad number in column %d", path, (long long)line_no, 3 + k);
             prices[rows * 4 + k] = v;
         }
-        const uint64_t key = fnv1a(fb[0], fe_[0]);
+        const uint64_t key = (uint64_t)date_join_key(fb[0], fe_[0]);
         auto it = days.find(key);
         int64_t id;
         if (it == days.end()) {
@@ -166,7 +206,7 @@ int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_onl
             id = it->second;
         }
         day_id[rows] = id;
-        if (date_key) date_key[rows] = (int64_t)(key >> 1);
+        if (date_key) date_key[rows] = (int64_t)key;
         second_of_day[rows] = sec;
         ++rows;
     }

@@ -44,12 +44,16 @@ constexpr int kBlock = 256;
 #ifndef FE_MIN_WAVES_PER_EU
 #define FE_MIN_WAVES_PER_EU 7
 #endif
-// Cache policy of the observation stores.  -2 (default) = chosen per kernel variant: plain global
-// stores for single-asset envs, non-temporal buffer stores (aux 2) for multi-asset envs, whose
-// log-return tables (tens of MB) must survive in the 4 MiB L2 next to a 20-150 GB store stream:
-// measured at 1M envs x 30 assets (tools/store_policy_box.sh) FETCH_SIZE 6.9 GiB -> 0.4 GiB per
-// launch and 26.4 -> 25.0 ms; sc1 (16) gives the same fetch reduction but 25.6 ms; no effect at 1 asset.
-// -1 = plain everywhere; >= 0 = buffer stores with that aux everywhere (experiments).
+// Cache policy of the observation stores (raw buffer stores, aux bits: 1 = sc0, 2 = nt, 16 = sc1).
+// -2 (default) = chosen per kernel variant; in both cases the point is that a 0.17-150 GB store stream must not
+// evict what phase 1 and phase 2 re-read every step from the 4 MiB L2s:
+//   * single-asset envs: sc1 (write-through, the line is dropped from L2).  The per-env state, the action and
+//     the tables then stay L2-resident, which shortens the kernel's start-up chain (index load -> bar gather ->
+//     accounting -> first store): measured at 64k envs (tools/ab_step.py, interleaved in one process, three
+//     boxes) 34.8 -> 31.1, 34.5 -> 32.0, 34.8 -> 33.6 us per step; nt gains about 1 % less, sc0|sc1 the same.
+//   * multi-asset envs: nt.  Measured at 1M envs x 30 assets (round 1, tools/store_policy_box.sh): FETCH_SIZE
+//     6.9 GiB -> 0.4 GiB per launch and 26.4 -> 25.0 ms; sc1 gives the same fetch reduction but 25.6 ms.
+// -1 = plain everywhere; >= 0 = that aux everywhere (experiment builds).
 // "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their
 // -D set here and are only ever loaded by explicit path
 #ifndef FE_BUILD_TAG
@@ -57,6 +61,32 @@ constexpr int kBlock = 256;
 #endif
 #ifndef FE_STORE_AUX
 #define FE_STORE_AUX -2
+#endif
+// Structure of the single-asset step kernel (experiments; tools/ab_step.py):
+//   0  software pipeline: per tile [account (wave 0) | barrier | stream (4 waves) | barrier], next tile's
+//      loads prefetched under the stream
+//   1  up-front accounting: wave w accounts the workgroup's w-th tile, all four at once; one barrier; then the
+//      workgroup streams its tiles back to back with no further barriers
+#ifndef FE_STEP_VARIANT
+#define FE_STEP_VARIANT 0
+#endif
+// Timing-only ablations of the step kernel (WRONG outputs; experiment builds only -- tools/ab_step.py):
+//   bit 0  no phase 1: descriptors fabricated from the env number, no state / bar loads, no write-back
+//   bit 1  no table loads in phase 2 (the image is built from constants)
+//   bit 2  no LDS transpose in phase 2 (registers stored directly)
+//   bit 3  phase 1 without its global stores (state write-back, reward, done)
+//   bit 4  phase 1 without its global loads (constants instead)
+//   bit 5  phase 1 without the accounting arithmetic
+//   bit 6  no phase 1 (nor its loads) for a workgroup's FIRST tile only   (is it the start-up chain?)
+//   bit 7  no phase 1 (nor its loads) for all tiles BUT the first         (or the per-tile bubbles?)
+#ifndef FE_ABLATE
+#define FE_ABLATE 0
+#endif
+// Diagnostic build: every workgroup of the single-asset step kernel writes four s_memrealtime stamps (100 MHz)
+// -- start, first tile accounted, first tile streamed, end -- into the buffer bound as fe_env_bind_stats'
+// eval_return argument (grid * 8 u64; the statistics themselves are off in this build).  tools/stamp_step.py.
+#ifndef FE_STAMP
+#define FE_STAMP 0
 #endif
 
 thread_local char g_err[512] = "";
@@ -150,6 +180,28 @@ __device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t counter) 
 // max(x, 0) that lets a NaN through, as torch.relu does
 __device__ __forceinline__ float relu32(float x) { return x > 0.0f ? x : (x != x ? x : 0.0f); }
 __device__ __forceinline__ double relu64(double x) { return x > 0.0 ? x : (x != x ? x : 0.0); }
+
+// Workgroup barrier that orders LDS traffic only.  Everything the waves of a workgroup hand to each other inside
+// these kernels goes through LDS (descriptors, sleeve rewards / flags, actions); their global stores are
+// fire-and-forget and nothing in the same launch reads them back.  __syncthreads() would also wait for every
+// outstanding global store of the wave (s_waitcnt vmcnt(0)): in the step kernel that drains the observation
+// store stream at every tile boundary and puts a store acknowledgement on the start-up chain.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// the step kernel's barriers (FE_SYNC=1: the round-1 form, for A/B)
+#ifndef FE_SYNC
+#define FE_SYNC 0
+#endif
+__device__ __forceinline__ void tile_barrier() {
+#if FE_SYNC
+    __syncthreads();
+#else
+    lds_barrier();
+#endif
+}
 
 struct Sleeve {
     float cash, lng, sht;
@@ -269,6 +321,9 @@ __host__ __device__ inline size_t lds_bytes(int EB, int A) {
     size_t S = (size_t)EB * A;
     size_t b = 4 * (size_t)kStageBytes + (size_t)EB * 8 + S * 8;
     if (A > 1) b += S * 8 + S * 4 + S * 4 + (size_t)EB * 4;
+#if FE_STEP_VARIANT == 1
+    if (A == 1) b = 4 * (size_t)kStageBytes + 4 * ((size_t)EB * 16);  // descriptors of four tiles at once
+#endif
     return (b + 15) & ~(size_t)15;
 }
 
@@ -305,15 +360,40 @@ struct SleeveIn {
 __device__ __forceinline__ void load_head(const Params &p, bool active, int64_t n, int64_t &idx, int64_t &spot) {
     idx = 0;
     spot = 0;
+#if FE_ABLATE & 16
+    idx = n % p.D;
+    spot = 1;
+    return;
+#endif
     if (active) {
         idx = p.env_idx[n];
         spot = p.spot0[n];
     }
 }
 
-__device__ __forceinline__ void load_body(const Params &p, int A, int a, bool active, int64_t sl, int64_t idx,
-                                          int64_t spot, SleeveIn &in) {
+// the part of the body that needs no index: account state of the sleeve (issued together with the head for a
+// workgroup's first tile, so that only the L2-resident bar gather sits behind the index load)
+__device__ __forceinline__ void load_state(const Params &p, bool active, int64_t sl, SleeveIn &in) {
     if (!active) return;
+#if FE_ABLATE & 16
+    in.cash = 1e4f; in.lng = (float)(sl & 3); in.sht = 0.0f; in.margin = 0.0;
+    return;
+#endif
+    in.cash = p.cash[sl];
+    in.lng = p.lng[sl];
+    in.sht = p.sht[sl];
+    in.margin = p.margin[sl];
+}
+
+// the part that does: the bar at the window's last row and the NaN probe of the next row
+__device__ __forceinline__ void load_bar(const Params &p, int A, int a, bool active, int64_t idx, int64_t spot,
+                                         SleeveIn &in) {
+    if (!active) return;
+#if FE_ABLATE & 16
+    in.idx = idx; in.s0 = spot + 1; in.nxt = spot + p.W + 1; in.bar = make_double4(100.0, 101.0, 99.0, 100.5);
+    in.probe = 0.0;
+    return;
+#endif
     const int64_t rs = 4 * (int64_t)A;
     const int64_t L = p.L;
     in.idx = idx;
@@ -324,10 +404,12 @@ __device__ __forceinline__ void load_body(const Params &p, int A, int a, bool ac
     in.bar = *reinterpret_cast<const double4 *>(p.P + (idx * L + last) * rs + 4 * a);
     in.probe = 0.0;
     if (in.nxt < L) in.probe = p.LR[(idx * L + in.nxt) * rs + 4 * a];
-    in.cash = p.cash[sl];
-    in.lng = p.lng[sl];
-    in.sht = p.sht[sl];
-    in.margin = p.margin[sl];
+}
+
+__device__ __forceinline__ void load_body(const Params &p, int A, int a, bool active, int64_t sl, int64_t idx,
+                                          int64_t spot, SleeveIn &in) {
+    load_bar(p, A, a, active, idx, spot, in);
+    load_state(p, active, sl, in);
 }
 
 // Phases 1 and 1b for one tile from preloaded inputs: every thread of the workgroup must call it
@@ -351,7 +433,11 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
         s.lng = in.lng;
         s.sht = in.sht;
         s.margin = in.margin;
+#if FE_ABLATE & 32
+        s.pos_obs = in.bar.w + (double)action; s.rew = in.bar.x; s.bankrupt = false;
+#else
         sleeve_step(p, action, in.bar.x, in.bar.y, in.bar.z, in.bar.w, s);
+#endif
         // termination: bankrupt | end of buffer | next open log-return is NaN, TSE:477-496
         sdone = s.bankrupt | (in.nxt >= L) | (in.probe != in.probe);
         l.pos[e * A + a] = s.pos_obs;
@@ -368,7 +454,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
     }
     // ---------------- phase 1b: one lane per env ----------------
     bool any = sdone;
-    if constexpr (!SINGLE) __syncthreads();
+    if constexpr (!SINGLE) tile_barrier();
     if (active && a == 0) {
         double rew;
         if constexpr (SINGLE) {
@@ -393,7 +479,9 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
                 p.counters[1] = ctr + 1;
             }
         }
+#if !(FE_ABLATE & 8)
         p.spot0[n] = s0;
+#endif
         if (p.evaluate) {  // TSE:523-536
             const bool term = p.terminated[n] != 0;
             if (term) rew = 0.0;
@@ -403,8 +491,12 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             }
             p.ep_ret[n] = (float)((double)p.ep_ret[n] + rew);
         }
+#if FE_ABLATE & 8
+        if (rew == 123.456) done_out[n] = 7;  // keeps the arithmetic alive
+#else
         rew_out[n] = rew;
         done_out[n] = any ? 1 : 0;
+#endif
         if (p.run_ret) {  // PPO_agent.py:120-132 without its per-step host sync
             float cr = (float)((double)p.run_ret[n] + rew);
             if (any) {
@@ -422,9 +514,13 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
         }
     }
     if constexpr (!SINGLE) {
-        __syncthreads();
+        tile_barrier();
         if (active) any = l.any[e] != 0;
     }
+#if FE_ABLATE & 8
+    if (active && s.cash == 123.456f && s.margin == 7.0) p.cash[sl] = s.lng + s.sht;
+    if (false)
+#endif
     if (active) {  // state write-back with the episodic reset folded in, TSE:498-502
         p.cash[sl] = any ? p.S32 : s.cash;
         p.lng[sl] = any ? 0.0f : s.lng;
@@ -485,6 +581,10 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
             const uint32_t ee = fdiv(tc, p.div_WA);           // env within the tile
             const uint32_t r = tc - ee * WA;                  // (row j, asset a) = r / A, r % A
             const uint32_t aa = SINGLE ? 0u : r - fdiv(r, p.div_A) * (uint32_t)A;
+#if FE_ABLATE & 2
+            v[gi].x = (decltype(v[gi].x))tc; v[gi].y = v[gi].x; v[gi].z = v[gi].x; v[gi].w = v[gi].x;
+            if (false)
+#endif
             if constexpr (sizeof(OT) == 4) {
                 if (narrow) {
                     v[gi] = *reinterpret_cast<const float4 *>(p.LR32 + l.src[ee] + 4u * r);
@@ -497,6 +597,21 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
             }
             pz[gi] = l.pos[ee * A + aa];
         }
+#if FE_ABLATE & 4
+        {
+            const uint32_t left_ = tuples - base;
+            const uint32_t nvalid_ = (left_ < (uint32_t)TPI ? left_ : (uint32_t)TPI) * 5u / VEC;
+            Pack<OT, VEC> *o_ = reinterpret_cast<Pack<OT, VEC> *>(dst + (size_t)base * 5u);
+#pragma unroll
+            for (int i = 0; i < TPI * 5 / VEC / 64; ++i) {
+                const uint32_t c = (uint32_t)lane + 64u * i;
+                Pack<OT, VEC> pk;
+                for (int q = 0; q < VEC; ++q) pk.v[q] = (OT)(q & 1 ? v[i % G].y : v[i % G].x) + (OT)pz[i % G];
+                if (c < nvalid_) o_[c] = pk;
+            }
+            continue;
+        }
+#endif
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
             OT *w = stage + (gi * 64 + lane) * 5;
@@ -512,7 +627,7 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
         const Pack<OT, VEC> *rd = reinterpret_cast<const Pack<OT, VEC> *>(stage);
         Pack<OT, VEC> *o = reinterpret_cast<Pack<OT, VEC> *>(dst + (size_t)base * 5u);
         constexpr int kStores = TPI * 5 / VEC / 64;  // 5 full-width store instructions at 16 B/lane
-        constexpr int kAux = FE_STORE_AUX == -2 ? (SINGLE ? -1 : 2) : FE_STORE_AUX;
+        constexpr int kAux = FE_STORE_AUX == -2 ? (SINGLE ? 16 : 2) : FE_STORE_AUX;
         if constexpr (kAux >= 0 && sizeof(OT) * VEC == 16) {
             // observation stores with explicit cache bits (aux: 1 = sc0, 2 = nt, 16 = sc1) through a
             // buffer descriptor over this wavefront's 5-KiB slab; the descriptor is wave-uniform
@@ -559,10 +674,10 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
             const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
             const int64_t n = n0 + e;
             describe_tile(p, l, A, e, a, e < ebt, n, n * A + a);
-            __syncthreads();
+            tile_barrier();
             stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
                                          reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
-            __syncthreads();  // LDS is reused by the next tile
+            tile_barrier();  // LDS is reused by the next tile
         }
     } else if constexpr (!SINGLE) {
         // multi-asset tiles stream hundreds of KiB each: phase 1 is <1 % of a tile, no pipelining needed
@@ -575,8 +690,58 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
             account_tile<SINGLE>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
             stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
                                          reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
-            __syncthreads();  // LDS is reused by the next tile
+            tile_barrier();  // LDS is reused by the next tile
         }
+#if FE_ABLATE & 1
+    } else if constexpr (SINGLE) {
+        for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+            const int64_t n0 = tile * EB;
+            const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+            if (e < ebt) {
+                l.src[e] = (((n0 + e) % p.D) * p.L + 1) * 4;
+                l.pos[e] = (double)e;
+            }
+            tile_barrier();
+            stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
+            tile_barrier();
+        }
+#elif FE_STEP_VARIANT == 1
+    } else if constexpr (SINGLE) {
+        // Up-front accounting.  A round = up to four of this workgroup's tiles: wave w runs phase 1 for tile w of
+        // the round on its first EB lanes (EB <= 64), all four waves at once -- one latency chain (index load ->
+        // bar gather -> accounting) per ROUND instead of per tile --, then one barrier, then the tiles stream out
+        // back to back.  Most shapes need a single round.
+        const int64_t G = gridDim.x;
+        int64_t *s_src = reinterpret_cast<int64_t *>(smem + 4 * kStageBytes);  // [4][EB]
+        double *s_pos = reinterpret_cast<double *>(s_src + 4 * EB);            // [4][EB]
+        for (int64_t t0 = blockIdx.x; t0 < p.num_tiles; t0 += 4 * G) {
+            {
+                const int64_t tile = t0 + (int64_t)wave * G;
+                const int64_t n = tile * EB + lane;
+                const bool act = tile < p.num_tiles && lane < EB && n < p.N;
+                TileLds lw;
+                lw.src = s_src + wave * EB;
+                lw.pos = s_pos + wave * EB;
+                lw.rew = nullptr; lw.shr = nullptr; lw.flg = nullptr; lw.any = nullptr;
+                account_tile<true>(p, lw, 1, lane, 0, act, n, n, act ? p.actions[n] : 0.0f, p.rew, p.done);
+            }
+            tile_barrier();
+#pragma unroll 1
+            for (int j = 0; j < 4; ++j) {
+                const int64_t tile = t0 + (int64_t)j * G;
+                if (tile >= p.num_tiles) break;
+                const int64_t n0 = tile * EB;
+                const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+                TileLds lj;
+                lj.src = s_src + j * EB;
+                lj.pos = s_pos + j * EB;
+                lj.rew = nullptr; lj.shr = nullptr; lj.flg = nullptr; lj.any = nullptr;
+                stream_tile<OT, VEC, SINGLE>(p, lj, stage, 1, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems,
+                                             lane, wave);
+            }
+            tile_barrier();  // descriptors are reused by the next round
+        }
+#endif
     } else {
         // Software pipeline over this workgroup's tiles: while tile i streams its observation
         // (phase 2, the long part), the state + bar gathers of tile i+1 and the index loads of tile
@@ -590,43 +755,101 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
             act = t < p.num_tiles && (int64_t)e < (left < (int64_t)EB ? left : (int64_t)EB);
             return n0 + e;
         };
+#if FE_STAMP
+        unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.stat_eval);
+        if (stamps && tid == 0) stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+#endif
         bool act0, act1, act2;
         int64_t n_cur = env_of(tile, act0), n_nxt = env_of(tile + G, act1), n_nn;
         int64_t idx1, spot1, idx2, spot2;
         SleeveIn in_cur, in_nxt;
         float action_cur = 0.0f, action_nxt = 0.0f;
+#if FE_ABLATE & (64 | 128)
+        const bool skip_first = (FE_ABLATE & 64) != 0, skip_rest = (FE_ABLATE & 128) != 0;
+        auto fake = [&](int64_t t) {
+            const int64_t n0f = t * EB;
+            if (n0f + e < p.N && e < EB) {
+                l.src[e] = (((n0f + e) % p.D) * p.L + 1) * 4;
+                l.pos[e] = (double)e;
+            }
+        };
+        if (!skip_first) {
+#endif
+        // first tile: everything that needs no index goes out with the index loads (one round trip), only the
+        // bar gather (an L2 hit) waits for them
         load_head(p, act0, n_cur, idx1, spot1);
-        load_body(p, A, a, act0, n_cur * A + a, idx1, spot1, in_cur);
+        load_state(p, act0, n_cur * A + a, in_cur);
         if (act0) action_cur = p.actions[n_cur * A + a];
+#if FE_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stamps && tid == 0) stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+#endif
+        load_bar(p, A, a, act0, idx1, spot1, in_cur);
+#if FE_STAMP
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (stamps && tid == 0) stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+#endif
+#if FE_ABLATE & (64 | 128)
+        }
+        if (!skip_rest)
+#endif
         load_head(p, act1, n_nxt, idx1, spot1);
         for (; tile < p.num_tiles; tile += G) {
             const int64_t n0 = tile * EB;
             const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+#if FE_ABLATE & (64 | 128)
+            const bool first = tile == (int64_t)blockIdx.x;
+            if (first ? skip_first : skip_rest) {
+                fake(tile);
+                tile_barrier();
+                if (first && !skip_rest) {  // the pipeline's prefetches for tile 2 still have to be issued
+                    load_body(p, A, a, act1, n_nxt * A + a, idx1, spot1, in_nxt);
+                    if (act1) action_nxt = p.actions[n_nxt * A + a];
+                    n_nn = env_of(tile + 2 * G, act2);
+                    load_head(p, act2, n_nn, idx2, spot2);
+                }
+                stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
+                tile_barrier();
+                in_cur = in_nxt; action_cur = action_nxt; n_cur = n_nxt; act0 = act1; n_nxt = n_nn; act1 = act2; idx1 = idx2; spot1 = spot2;
+                continue;
+            }
+#endif
             account_core<SINGLE>(p, l, A, e, a, act0, n_cur, n_cur * A + a, in_cur, action_cur, p.rew, p.done);
-            if constexpr (SINGLE) __syncthreads();
+            if constexpr (SINGLE) tile_barrier();
+#if FE_STAMP
+            if (stamps && tid == 0 && tile == (int64_t)blockIdx.x) stamps[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
             // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
+#if FE_ABLATE & 128
+            if (false) {
+#endif
             load_body(p, A, a, act1, n_nxt * A + a, idx1, spot1, in_nxt);
             if (act1) action_nxt = p.actions[n_nxt * A + a];
             n_nn = env_of(tile + 2 * G, act2);
             load_head(p, act2, n_nn, idx2, spot2);
+#if FE_ABLATE & 128
+            }
+            n_nn = env_of(tile + 2 * G, act2);
+#endif
             stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
                                          reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
-            __syncthreads();  // LDS is reused by the next tile
+            tile_barrier();  // LDS is reused by the next tile
+#if FE_STAMP
+            if (stamps && tid == 0 && tile == (int64_t)blockIdx.x) stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
+#endif
             in_cur = in_nxt;
             action_cur = action_nxt;
             n_cur = n_nxt; act0 = act1;
             n_nxt = n_nn; act1 = act2;
             idx1 = idx2; spot1 = spot2;
         }
+#if FE_STAMP
+        if (stamps && tid == 0) {
+            __builtin_amdgcn_s_waitcnt(0);  // this wavefront's stores have left
+            stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
+        }
+#endif
     }
-}
-
-// Workgroup barrier that orders LDS traffic only: the fused rollout keeps all cross-lane traffic in
-// LDS, so it must not wait for its (fire-and-forget) global stores the way __syncthreads() does.
-__device__ __forceinline__ void lds_barrier() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
 }
 
 // Register-resident account state of one sleeve across the K steps of a fused rollout.
@@ -1232,7 +1455,10 @@ static int configure_launch(fe_env *env) {
     const int A = cfg.A;
     const void *kern = kernel_for<false>(cfg.obs_is_f32 != 0, env->vec, A == 1);
     // How many workgroups the chip holds at once for this kernel variant (registers + LDS).
-    const int64_t cap = kBlock / A > 0 ? kBlock / A : 1;  // one sleeve per lane in phase 1
+    int64_t cap = kBlock / A > 0 ? kBlock / A : 1;  // one sleeve per lane in phase 1
+#if FE_STEP_VARIANT == 1
+    if (A == 1) cap = 64;  // a tile is accounted by one wavefront
+#endif
     int per_cu = 0;
     hipError_t he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes((int)cap, A));
     if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
@@ -1416,9 +1642,15 @@ int fe_env_bind_stats(fe_env *env, float *running_returns, double *accumulators,
         return FE_OK;
     }
     if (!accumulators || !eval_return) return fail(FE_ERR_ARG, "fe_env_bind_stats: null accumulator pointer");
+#if FE_STAMP
+    env->p.run_ret = nullptr;  // statistics off; eval_return carries the stamp buffer
+    env->p.stat_acc = nullptr;
+    env->p.stat_eval = eval_return;
+#else
     env->p.run_ret = running_returns;
     env->p.stat_acc = accumulators;
     env->p.stat_eval = eval_return;
+#endif
     return FE_OK;
 }
 

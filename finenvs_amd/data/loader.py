@@ -109,15 +109,22 @@ def read_csv_portfolio(paths: Sequence[str]) -> Tuple[np.ndarray, np.ndarray, np
     if len(paths) == 1:
         return read_csv_series(paths[0])
     parts = [_read_native(p) for p in paths]
-    # join key: (date text hash, second of day); a day has < 86400 seconds
+    # join key: (date key < 2^45, second of day < 2^17) -- no int64 wrap; the date key is the calendar date
+    # itself where the text is one (fe_csv.cpp date_join_key), so files spelling dates differently still join
     jk = [key * 131072 + sec for _, _, key, sec in parts]
+    for path, k in zip(paths, jk):
+        if np.unique(k).size != k.size:
+            raise Exception(f"{path}: duplicate (date, time) rows -- cannot join it on a shared calendar")
     common = jk[0]
     for k in jk[1:]:
         common = common[np.isin(common, k)]
+    if common.size == 0:
+        raise Exception("portfolio join is empty: the files " + ", ".join(paths) + " share no (date, time) row")
     cols = []
     for (prices, _, _, _), k in zip(parts, jk):
         order = np.argsort(k, kind="stable")
         pos = order[np.searchsorted(k[order], common)]
+        assert np.array_equal(k[pos], common)  # every matched row carries exactly the joined (date, time)
         cols.append(prices[pos])
     sel = np.isin(jk[0], common)
     day0, sec0 = parts[0][1][sel], parts[0][3][sel]

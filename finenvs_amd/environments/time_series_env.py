@@ -68,6 +68,7 @@ class TimeSeriesEnv:
         env_indices=None,
         rank: int = 0,
         world_size: int = 1,
+        _native=None,
     ):
         self.instrument_name = instrument_name if isinstance(instrument_name, str) else "+".join(instrument_name)
         self.num_intervals = int(num_intervals)
@@ -94,7 +95,9 @@ class TimeSeriesEnv:
             self.data_dir_name = loader.get_data_dir_name(names[0])
             self.filename = [loader.find_file_by_key(loader.get_data_dir_name(n), self.file_key) for n in names]
         self.device = set_device(device_id)
-        self._lib = _lib.load()
+        # _native: a library handle from _lib.load(path) -- how tools/ A/B an experiment build against the
+        # product in one process; everything else gets the product library
+        self._lib = _native if _native is not None else _lib.load()
         self._dev = torch.device(self.device)
         self._dev_index = int(device_id)
         with torch.cuda.device(self._dev):

@@ -245,8 +245,10 @@ int fe_traj_returns(const double *rewards, const int32_t *dones, const float *va
  * Rows are Date,Time,Open,High,Low,Close,Volume.  ALL POINTERS HERE ARE HOST POINTERS.
  * fe_csv_count_lines gives an upper bound for `capacity`.  fe_csv_read fills
  * prices (rows, 4) f64 = O,H,L,C, day_id (rows) = index of the row's date in order of
- * first appearance, date_key (rows; may be NULL) = 63-bit FNV-1a hash of the date text
- * (equal text <=> equal key, usable to join files), second_of_day (rows); with
+ * first appearance, date_key (rows; may be NULL) = join key of the row's date, < 2^45: yyyymmdd when
+ * the text is a calendar date (YYYY-MM-DD or MM/DD/YYYY, either separator -- so files that spell
+ * dates differently still join), else 2^44 + 44 bits of the text's FNV-1a hash; date_key * 2^17 +
+ * second_of_day is a collision-free-by-construction row key for calendar dates; second_of_day (rows); with
  * market_hours_only != 0 only rows with 09:30:00 <= time <= 15:59:00 are kept.
  * Both return the row count, or a negative FE_ERR_* code.
  */

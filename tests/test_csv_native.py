@@ -95,3 +95,43 @@ def test_native_reader_reproduces_reference_frames(tmp_path):
     assert_bits(got, g["ref_dataset"], "the frame the reference built from the same CSV")
     s, e, L = loader.episode_bounds(d, int(g["W"]))
     assert_bits(s, g["ref_start_indices"]); assert_bits(e, g["ref_stop_indices"])
+
+
+REF_DATA = "/root/reference/finenvs/data"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_DATA), reason="the reference tree exists in the build container only")
+@pytest.mark.parametrize("inst,fixture", [("OIH", "tables_oih.npz"), ("IBM", "tables_ibm.npz"), ("SPY", "tables_spy.npz")])
+def test_native_reader_on_the_references_own_files(inst, fixture):
+    """fe_csv_read on the three real files the reference's unit test builds (tests/unit/test_time_series_env.py:
+    10-14) -- MM/DD/YYYY + HH:MM (IBM, OIH), YYYY-MM-DD + HH:MM:SS with 04:00 pre-market rows (SPY) -- equals, bit
+    for bit, the frame the reference's pandas path kept (stored in the fixture by oracle/make_goldens.py), and the
+    episode bounds at the fixture's window equal the reference's bounds cache."""
+    g = load_golden(fixture)
+    prices, day_id, sec = loader.read_csv_series(os.path.join(REF_DATA, inst, "dummy.csv"))
+    assert_bits(prices, g["ref_dataset"], "market-hours OHLC rows")
+    assert_bits(day_id, g["series_day_id"], "day ids by first appearance")
+    assert_bits(sec, g["series_second"], "second of day")
+    starts, stops, L = loader.episode_bounds(day_id, int(g["W"]))
+    assert_bits(starts, g["ref_start_indices"]); assert_bits(stops, g["ref_stop_indices"])
+    assert L == int(g["ref_max_length"])
+
+
+def test_portfolio_join_across_date_spellings_and_its_errors(tmp_path):
+    a = ["2022-04-01,09:30:00,1,1,1,1,5", "2022-04-01,09:31:00,2,2,2,2,5", "2022-04-04,09:30:00,3,3,3,3,5"]
+    b = ["04/01/2022,09:30,10,10,10,10,5", "04/01/2022,09:32,20,20,20,20,5", "04/04/2022,09:30,30,30,30,30,5"]
+    pa, pb = str(tmp_path / "data" / "A" / "dummy.csv"), str(tmp_path / "data" / "B" / "dummy.csv")
+    _write(pa, a); _write(pb, b)
+    prices, day, sec = loader.read_csv_portfolio([pa, pb])
+    assert prices[:, 0].tolist() == [1, 3] and prices[:, 4].tolist() == [10, 30]   # rows present in both files
+    assert day.tolist() == [0, 1] and sec.tolist() == [34200, 34200]
+    _write(pb, ["05/01/2022,09:30,10,10,10,10,5"])
+    with pytest.raises(Exception, match="join is empty"):
+        loader.read_csv_portfolio([pa, pb])
+    _write(pb, b + [b[0]])
+    with pytest.raises(Exception, match="duplicate"):
+        loader.read_csv_portfolio([pa, pb])
+    # opaque (non-calendar) date texts still work as keys: equal text joins
+    _write(pa, ["dayA,09:30,1,1,1,1,5", "dayB,09:30,2,2,2,2,5"]); _write(pb, ["dayB,09:30,7,7,7,7,5"])
+    prices, day, _ = loader.read_csv_portfolio([pa, pb])
+    assert prices.tolist() == [[2, 2, 2, 2, 7, 7, 7, 7]]
