@@ -53,7 +53,8 @@ constexpr int kBlock = 256;
 //     boxes) 34.8 -> 31.1, 34.5 -> 32.0, 34.8 -> 33.6 us per step; nt gains about 1 % less, sc0|sc1 the same.
 //   * multi-asset envs: nt.  Measured at 1M envs x 30 assets (round 1, tools/store_policy_box.sh): FETCH_SIZE
 //     6.9 GiB -> 0.4 GiB per launch and 26.4 -> 25.0 ms; sc1 gives the same fetch reduction but 25.6 ms.
-// -1 = plain everywhere; >= 0 = that aux everywhere (experiment builds).
+// -1 = plain everywhere; -3 = the round-1 choice (plain for single-asset, nt for multi-asset); >= 0 = that aux
+// everywhere (experiment builds).
 // "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their
 // -D set here and are only ever loaded by explicit path
 #ifndef FE_BUILD_TAG
@@ -627,7 +628,7 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
         const Pack<OT, VEC> *rd = reinterpret_cast<const Pack<OT, VEC> *>(stage);
         Pack<OT, VEC> *o = reinterpret_cast<Pack<OT, VEC> *>(dst + (size_t)base * 5u);
         constexpr int kStores = TPI * 5 / VEC / 64;  // 5 full-width store instructions at 16 B/lane
-        constexpr int kAux = FE_STORE_AUX == -2 ? (SINGLE ? 16 : 2) : FE_STORE_AUX;
+        constexpr int kAux = FE_STORE_AUX == -2 ? (SINGLE ? 16 : 2) : (FE_STORE_AUX == -3 ? (SINGLE ? -1 : 2) : FE_STORE_AUX);
         if constexpr (kAux >= 0 && sizeof(OT) * VEC == 16) {
             // observation stores with explicit cache bits (aux: 1 = sc0, 2 = nt, 16 = sc1) through a
             // buffer descriptor over this wavefront's 5-KiB slab; the descriptor is wave-uniform
