@@ -48,6 +48,7 @@ SIGNATURES = {
     "fe_env_rollout_linear": (C.c_int, [_vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_policy_table": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "fe_env_rollout_table": (C.c_int, [_vp, _vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fe_env_rollout_mlp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_env_set_day": (C.c_int, [_vp, _i64, _i64, _vp]),
     "fe_env_launch_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "fe_env_destroy": (C.c_int, [_vp]),

@@ -68,6 +68,8 @@ constexpr int kBlock = 256;
 //      loads prefetched under the stream
 //   1  up-front accounting: wave w accounts the workgroup's w-th tile, all four at once; one barrier; then the
 //      workgroup streams its tiles back to back with no further barriers
+//   2  the north star's literal "one wavefront per env": lane 0 of a wavefront accounts one env, then the
+//      wavefront streams that env's observation; no workgroup barriers at all (measured A/B for DESIGN.md)
 #ifndef FE_STEP_VARIANT
 #define FE_STEP_VARIANT 0
 #endif
@@ -324,6 +326,8 @@ __host__ __device__ inline size_t lds_bytes(int EB, int A) {
     if (A > 1) b += S * 8 + S * 4 + S * 4 + (size_t)EB * 4;
 #if FE_STEP_VARIANT == 1
     if (A == 1) b = 4 * (size_t)kStageBytes + 4 * ((size_t)EB * 16);  // descriptors of four tiles at once
+#elif FE_STEP_VARIANT == 2
+    if (A == 1 && b < 4 * (size_t)kStageBytes + 64) b = 4 * (size_t)kStageBytes + 64;  // one descriptor slot per wavefront
 #endif
     return (b + 15) & ~(size_t)15;
 }
@@ -563,12 +567,12 @@ __device__ __forceinline__ void describe_tile(const Params &p, const TileLds &l,
 // private LDS image.  No workgroup barrier inside.
 template <typename OT, int VEC, bool SINGLE>
 __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, OT *stage, int A, int ebt, OT *dst,
-                                            int lane, int wave) {
+                                            int lane, int wave, int nwaves = kBlock / 64) {
     constexpr int TPI = kStageBytes / (5 * (int)sizeof(OT));  // tuples per wave iteration
     constexpr int G = TPI / 64;                                // tuples per lane per iteration
     const uint32_t WA = (uint32_t)p.W * (uint32_t)A;           // 32-byte table tuples per env
     const uint32_t tuples = (uint32_t)ebt * WA;
-    for (uint32_t base = wave * TPI; base < tuples; base += 4 * TPI) {
+    for (uint32_t base = wave * TPI; base < tuples; base += nwaves * TPI) {
         // f32 observations read a pre-cast f32 copy of the table when one is bound: half the L2 traffic,
         // same values ((float) of the f64 entry either way)
         using TupleT = typename std::conditional<sizeof(OT) == 4, float4, double4>::type;
@@ -705,6 +709,22 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
             tile_barrier();
             stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
             tile_barrier();
+        }
+#elif FE_STEP_VARIANT == 2
+    } else if constexpr (SINGLE) {
+        // one wavefront per env: env = global wavefront index, grid-strided
+        int64_t *w_src = reinterpret_cast<int64_t *>(smem + 4 * kStageBytes) + wave;  // wave-private descriptor slot
+        double *w_pos = reinterpret_cast<double *>(smem + 4 * kStageBytes + 4 * 8) + wave;
+        TileLds lw;
+        lw.src = w_src; lw.pos = w_pos; lw.rew = nullptr; lw.shr = nullptr; lw.flg = nullptr; lw.any = nullptr;
+        const int64_t nw = (int64_t)gridDim.x * (kBlock / 64);
+        for (int64_t n = (int64_t)blockIdx.x * (kBlock / 64) + wave; n < p.N; n += nw) {
+            const bool act = lane == 0;
+            account_tile<true>(p, lw, 1, 0, 0, act, n, n, act ? p.actions[n] : 0.0f, p.rew, p.done);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            stream_tile<OT, VEC, SINGLE>(p, lw, stage, 1, 1, reinterpret_cast<OT *>(p.obs) + n * (int64_t)p.env_elems, lane, 0, 1);
         }
 #elif FE_STEP_VARIANT == 1
     } else if constexpr (SINGLE) {
@@ -1221,6 +1241,242 @@ __global__ __launch_bounds__(kBlock) void fe_rollout_table_kernel(const Params p
             }
         }
         if constexpr (!SINGLE) __syncthreads();
+    }
+}
+
+// ---- f2, MLP head: the observation projection as a dense GEMM on the matrix cores ----
+// For a two-layer perceptron on the flattened window (what an MLP actor of the reference sees after
+// states.float(), finenvs/agents/networks/multilayer_perceptron.py:17-25 with its default ELU,
+// finenvs/agents/PPO/PPO_agent.py:101) the first layer is a true dense contraction,
+//   pre[pair][h] = b1[h] + sum_{j<W} sum_{c<5} (float)obs[pair][j][c] * W1[5j+c][h],     (pairs) x (5W) x (H),
+// so it runs on MFMA -- v_mfma_f32_32x32x2_f32, f32 in / f32 accumulate, i.e. exactly an fmaf chain in k order
+// (cdna_hip_programming.md section 3), which makes the result bit-reproducible on the CPU:
+//   * D = W1t . X^T with the hidden units on the rows and 32 (env, asset) pairs on the columns of a tile, so that
+//     after the K loop every lane holds hidden units of ITS pair and the second layer is an in-lane dot product;
+//   * the position feature is the same in every window row: its W weights per hidden unit are pre-summed by the
+//     host (wpos[h]) and enter as the accumulator's start value fmaf((float)pos, wpos[h], b1[h]);
+//   * the remaining K4 = 4W log-return features are contracted in groups of two window rows: lane half 0 supplies
+//     row 2g, half 1 row 2g+1 (one 16-byte load per lane from the f32 table, straight from L2); the k order of
+//     the chain is therefore g ascending, then c = 0..3, then row 2g before row 2g+1;
+//   * W1t lives in LDS for the whole launch (rows padded by 16 bytes: conflict-free ds_read_b128 fragments).
+// action = clamp(b2 + [half 0: sum_h w2[h] act(pre[h])] + [half 1: ...], -1, 1); the in-lane order is tile by
+// tile, register by register (hidden unit 32t + (r&3) + 8(r>>2) + 4*half).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct MlpArgs {
+    const float *lr32;  // (D, L, 4A) f32 copy of the log-return table
+    const float *w1t;   // (H, 4W) f32, w1t[h][4j+c] = W1[5j+c][h], c < 4
+    const float *wpos;  // (H) f32, sum_j W1[5j+4][h]
+    const float *b1;    // (H)
+    const float *w2;    // (H)
+    float b2;
+    int32_t H, act, K;  // act: 0 ELU (the reference's default), 1 ReLU, 2 tanh
+    int64_t *obs_src;
+    double *obs_pos;
+    float *actions_out;
+    double *rew_out;
+    int32_t *done_out;
+};
+
+constexpr int kMlpChunk = 4;  // row groups (8 k each) per software-pipeline stage of the first layer
+// padded row length of W1t in LDS: whole chunks of zero-filled k, plus 16 bytes against bank conflicts
+__host__ __device__ inline int mlp_kp(int W) { return ((4 * W + 8 * kMlpChunk - 1) / (8 * kMlpChunk)) * (8 * kMlpChunk) + 4; }
+
+__host__ __device__ inline size_t mlp_lds_bytes(int EB, int A, int W, int H) {
+    size_t S = (size_t)EB * A;
+    size_t b = (size_t)EB * 8 + S * 8 + S * 8 + S * 4 + S * 4 + (size_t)EB * 4;  // TileLds
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)EB * 8;  // redrawn day per env
+    b += S * 4;           // actions
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)H * mlp_kp(W) * 4;  // W1t
+    b += 3 * (size_t)H * 4;          // wpos, b1, w2
+    return (b + 15) & ~(size_t)15;
+}
+
+template <int ACT>
+__device__ __forceinline__ float mlp_act(float z) {
+    if constexpr (ACT == 1) return z > 0.0f ? z : (z != z ? z : 0.0f);
+    if constexpr (ACT == 2) return tanhf(z);
+    // ELU, alpha = 1.  exp through v_exp_f32 (__expf), not expm1f: the second layer is VALU-bound (32 hidden units per
+    // lane and block) and expm1f costs ~25 instructions per unit; the absolute error of exp(z) - 1 is <= 2e-7 per
+    // unit (an ulp of 1.0), inside the 2e-6 tolerance of the action (tests/test_mlp_rollout_gpu.py)
+    return z > 0.0f ? z : __expf(z) - 1.0f;
+}
+
+// second layer for one lane: fmaf chain over this lane's hidden units, tile by tile, register by register
+template <int ACT, int NT>
+__device__ __forceinline__ float mlp_second_layer(const f32x16 (&acc)[NT], const float *s_w2, int half) {
+    float part = 0.0f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int h = 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+            part = fmaf(s_w2[h], mlp_act<ACT>(acc[t][rr]), part);
+        }
+    return part;
+}
+
+// Policy of one block of 32 (env, asset) pairs, run by one wavefront: first layer on the matrix cores, second
+// layer in-lane, action into s_act[q].  l_src / l_pos are the tile's observation descriptors in LDS.
+template <bool SINGLE, int NT>
+__device__ __forceinline__ void mlp_policy_block(const Params &p, const MlpArgs &r, const int64_t *l_src,
+                                                 const double *l_pos, float *s_act, const float *s_w1t,
+                                                 const float *s_wpos, const float *s_b1, const float *s_w2, int KP,
+                                                 int blk, int pairs, int lane) {
+    const int A = SINGLE ? 1 : p.A;
+    const int W = p.W;
+    const int col = lane & 31, half = lane >> 5;
+    const int ngroups = (4 * W + 7) / 8;  // two window rows per group
+    const int64_t rstride = 4 * (int64_t)A;
+    struct { const int64_t *src; const double *pos; } l = {l_src, l_pos};
+
+    const int q = blk * 32 + col;
+    const int qc = q < pairs ? q : pairs - 1;
+    const int ee = SINGLE ? qc : (int)fdiv((uint32_t)qc, p.div_A);
+    const int aa = SINGLE ? 0 : qc - ee * A;
+    const float *xsrc = r.lr32 + l.src[ee] + 4 * aa;
+    const float pos32 = (float)l.pos[qc];
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) {
+            const int h = 32 * t + (rr & 3) + 8 * (rr >> 2) + 4 * half;
+            acc[t][rr] = fmaf(pos32, s_wpos[h], s_b1[h]);
+        }
+    const float *wrow = s_w1t + (size_t)col * KP + 4 * half;
+    auto load_x = [&](int g) {
+        const int row = 2 * g + half;
+        float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (row < W) x = *reinterpret_cast<const float4 *>(xsrc + (int64_t)row * rstride);
+        return x;
+    };
+    // First layer.  B operands (window rows, from L2) are fetched one chunk of CH row groups ahead -- a
+    // chunk is CH * NT * 4 MFMAs of 64 cycles, several L2 round trips --; the chunk body has no control
+    // flow (rows past W read as zero, W1t is zero-padded to whole chunks), so the compiler is free to
+    // hoist the LDS fragment reads over the MFMAs.
+    constexpr int CH = kMlpChunk;
+    const int nchunks = (ngroups + CH - 1) / CH;
+    float4 xc[CH], xn[CH];
+#pragma unroll
+    for (int i = 0; i < CH; ++i) xc[i] = load_x(i);
+    for (int c = 0; c < nchunks; ++c) {
+#pragma unroll
+        for (int i = 0; i < CH; ++i) xn[i] = load_x((c + 1) * CH + i);
+#pragma unroll
+        for (int i = 0; i < CH; ++i) {
+            float4 wa[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+                wa[t] = *reinterpret_cast<const float4 *>(wrow + (size_t)(32 * t) * KP + 8 * (c * CH + i));
+            const float xs[4] = {xc[i].x, xc[i].y, xc[i].z, xc[i].w};
+#pragma unroll
+            for (int m = 0; m < 4; ++m)
+#pragma unroll
+                for (int t = 0; t < NT; ++t) {
+                    const float ws = m == 0 ? wa[t].x : (m == 1 ? wa[t].y : (m == 2 ? wa[t].z : wa[t].w));
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs[m], acc[t], 0, 0, 0);
+                }
+        }
+#pragma unroll
+        for (int i = 0; i < CH; ++i) xc[i] = xn[i];
+    }
+    // second layer: in-lane over this lane's hidden units, then the two halves of the pair
+    float part;
+    if (r.act == 1) part = mlp_second_layer<1, NT>(acc, s_w2, half);
+    else if (r.act == 2) part = mlp_second_layer<2, NT>(acc, s_w2, half);
+    else part = mlp_second_layer<0, NT>(acc, s_w2, half);
+    const float other = __shfl_xor(part, 32, 64);
+    const float tot = half == 0 ? part + other : other + part;  // always (half 0) + (half 1)
+    float a32 = r.b2 + tot;
+    a32 = a32 < -1.0f ? -1.0f : (a32 > 1.0f ? 1.0f : a32);
+    if (half == 0 && q < pairs) s_act[q] = a32;
+            }
+
+template <bool SINGLE, int NT>
+__global__ __launch_bounds__(kBlock, 2) void fe_rollout_mlp_kernel(const Params p, const MlpArgs r) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const int S = EB * A;
+    const int W = p.W;
+    constexpr int H = 32 * NT;
+    const TileLds l = carve_lds(smem, EB, S);
+    size_t off = (size_t)EB * 8 + (size_t)S * 8 + (size_t)S * 8 + (size_t)S * 4 + (size_t)S * 4 + (size_t)EB * 4;
+    off = (off + 7) & ~(size_t)7;
+    int64_t *l_idx = reinterpret_cast<int64_t *>(smem + off);
+    off += (size_t)EB * 8;
+    float *s_act = reinterpret_cast<float *>(smem + off);
+    off = (off + (size_t)S * 4 + 15) & ~(size_t)15;
+    const int KP = mlp_kp(W);
+    float *s_w1t = reinterpret_cast<float *>(smem + off);
+    float *s_wpos = s_w1t + (size_t)H * KP;
+    float *s_b1 = s_wpos + H;
+    float *s_w2 = s_b1 + H;
+    const int tid = threadIdx.x;
+    const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
+    const int a = SINGLE ? 0 : tid - e * A;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int64_t NA = p.N * A;
+    const int K4 = 4 * W;
+    for (int i = tid; i < H * KP; i += kBlock) {
+        const int h = i / KP, k = i - h * KP;
+        s_w1t[i] = k < K4 ? r.w1t[(size_t)h * K4 + k] : 0.0f;
+    }
+    for (int i = tid; i < H; i += kBlock) {
+        s_wpos[i] = r.wpos[i];
+        s_b1[i] = r.b1[i];
+        s_w2[i] = r.w2[i];
+    }
+
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        const bool active = e < ebt;
+        const int64_t n = n0 + e;
+        const int64_t sl = n * A + a;
+        SleeveReg st;
+        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
+        st.obs_row = 0; st.obs_pos = 0.0;
+        if (active) {
+            st.idx = p.env_idx[n];
+            st.spot = p.spot0[n];
+            st.cash = p.cash[sl];
+            st.lng = p.lng[sl];
+            st.sht = p.sht[sl];
+            st.margin = p.margin[sl];
+            if (a == 0) l.src[e] = r.obs_src[n];
+            l.pos[e * A + a] = r.obs_pos[sl];
+        }
+        __syncthreads();  // also covers the weight image on the first tile
+        const int pairs = ebt * A;
+        const int nblk = (pairs + 31) / 32;
+        for (int k = 0; k < r.K; ++k) {
+            // ---- policy: one wavefront per block of 32 pairs ----
+            for (int blk = wave; blk < nblk; blk += kBlock / 64)
+                mlp_policy_block<SINGLE, NT>(p, r, l.src, l.pos, s_act, s_w1t, s_wpos, s_b1, s_w2, KP, blk, pairs, lane);
+            lds_barrier();
+            const float act = active ? s_act[e * A + a] : 0.0f;
+            if (active && r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
+            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
+                                 r.done_out + (int64_t)k * p.N);
+            lds_barrier();  // the new observation's descriptors are complete
+        }
+        if (active) {  // state and descriptors go back to HBM once per launch
+            p.cash[sl] = st.cash;
+            p.lng[sl] = st.lng;
+            p.sht[sl] = st.sht;
+            p.margin[sl] = st.margin;
+            r.obs_pos[sl] = l.pos[e * A + a];
+            if (a == 0) {
+                p.env_idx[n] = st.idx;
+                p.spot0[n] = st.spot;
+                r.obs_src[n] = l.src[e];
+            }
+        }
+        __syncthreads();
     }
 }
 
@@ -1789,6 +2045,48 @@ int fe_env_rollout_table(fe_env *env, const double *table, const double *wsum, d
         hipLaunchKernelGGL(fe_rollout_table_kernel<false>, g, b, lds, (hipStream_t)stream, p, r);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_table launch");
+    return FE_OK;
+}
+
+int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, const float *wpos, const float *b1,
+                       const float *w2, float b2, int32_t H, int32_t activation, int32_t K, int64_t *obs_src,
+                       double *obs_pos, float *actions_out, double *rewards_out, int32_t *dones_out, void *stream) {
+    if (!env || !logret_f32 || !w1t || !wpos || !b1 || !w2 || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
+        return fail(FE_ERR_ARG, "fe_env_rollout_mlp: bad argument");
+    if (H != 32 && H != 64 && H != 128) return fail(FE_ERR_ARG, "fe_env_rollout_mlp: H must be 32, 64 or 128 (got %d)", (int)H);
+    if (activation < 0 || activation > 2) return fail(FE_ERR_ARG, "fe_env_rollout_mlp: activation must be 0 (ELU), 1 (ReLU) or 2 (tanh)");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_mlp: state not bound");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    Params p = env->p;
+    MlpArgs r;
+    r.lr32 = logret_f32; r.w1t = w1t; r.wpos = wpos; r.b1 = b1; r.w2 = w2; r.b2 = b2; r.H = H; r.act = activation; r.K = K;
+    r.obs_src = obs_src; r.obs_pos = obs_pos; r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
+    // 128 pairs per workgroup = four 32-pair MFMA column blocks, one per wavefront, two workgroups per CU.
+    // (A 512-thread form running policy and accounting of two sub-tiles in antiphase was tried and dropped: on
+    // gfx950 the f32-input MFMA executes on the vector ALUs -- SQ_VALU_MFMA_COEXEC_CYCLES = 0 -- so there is
+    // nothing for the accounting to hide behind; profiles/r02_microbench/mlp_prof.txt.)
+    int64_t cap = kBlock / p.A > 0 ? kBlock / p.A : 1;
+    int64_t eb = 128 / p.A;
+    if (eb < 1) eb = 1;
+    if (eb > cap) eb = cap;
+    if (env->rollout_tile_override > 0) eb = env->rollout_tile_override < cap ? env->rollout_tile_override : cap;
+    p.EB = (int)eb;
+    p.num_tiles = (p.N + eb - 1) / eb;
+    const size_t lds = mlp_lds_bytes(p.EB, p.A, p.W, H);
+    const bool single = p.A == 1;
+#define FE_MLP(NT) (single ? (const void *)fe_rollout_mlp_kernel<true, NT> : (const void *)fe_rollout_mlp_kernel<false, NT>)
+    const void *kern = H == 32 ? FE_MLP(1) : (H == 64 ? FE_MLP(2) : FE_MLP(4));
+#undef FE_MLP
+    const int64_t grid = p.num_tiles < 8 * 256 ? p.num_tiles : 8 * 256;
+    const int block = kBlock;
+    if (lds > 160 * 1024)
+        return fail(FE_ERR_ARG, "fe_env_rollout_mlp: W1 (%d x %d) does not fit the 160 KiB LDS (%zu bytes needed)", (int)H, 4 * p.W, lds);
+    hipError_t he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_mlp: hipFuncSetAttribute");
+    void *args[] = {&p, &r};
+    he = hipLaunchKernel(kern, dim3((unsigned)grid), dim3(block), args, lds, (hipStream_t)stream);
+    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_mlp launch");
     return FE_OK;
 }
 

@@ -177,3 +177,82 @@ class FusedLinearRollout:
         _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
                                                obs.data_ptr(), self.env._stream()))
         return obs
+
+
+class FusedMLPRollout:
+    """K env steps per launch with an in-kernel two-layer perceptron policy on the flattened observation window of
+    every (env, asset) pair (SURVEY.md 8f.2 "linear/MLP head"; C ABI ``fe_env_rollout_mlp``):
+
+        actions = clamp(W2 . act(W1^T . flatten(states.float()) + b1) + b2, -1, 1)
+
+    i.e. ``nn.Sequential(nn.Flatten(), nn.Linear(5W, H), act, nn.Linear(H, 1))`` of the reference's MLP networks
+    (finenvs/agents/networks/multilayer_perceptron.py:17-25, default ELU) applied per asset.  The first layer is a
+    dense (pairs x 5W x H) contraction on the MFMA units (f32 in / f32 accumulate); observations are never written
+    to HBM during the rollout.  ``W1`` is (5W, H) with rows in observation order (row 5j+c), ``b1``/``W2`` (H,),
+    ``H`` in {32, 64, 128}."""
+
+    ACTIVATIONS = {"elu": 0, "relu": 1, "tanh": 2}
+
+    def __init__(self, env, W1: torch.Tensor, b1: torch.Tensor, W2: torch.Tensor, b2: float = 0.0, activation: str = "elu"):
+        W = env.num_intervals
+        if W1.dim() != 2 or W1.shape[0] != 5 * W:
+            raise ValueError(f"W1 must be ({5 * W}, H): one row per flattened observation element")
+        H = int(W1.shape[1])
+        if H not in (32, 64, 128):
+            raise ValueError("H must be 32, 64 or 128")
+        if activation not in self.ACTIVATIONS:
+            raise ValueError(f"activation must be one of {sorted(self.ACTIVATIONS)}")
+        if env.redraw != "device" and not env.evaluate:
+            raise ValueError('the fused rollout needs redraw="device" (or evaluate mode): no host in the loop')
+        self.env, self.H, self.act = env, H, self.ACTIVATIONS[activation]
+        dev = env._dev
+        self.obs_src = torch.empty((env.num_envs,), dtype=torch.int64, device=dev)
+        self.obs_pos = torch.empty((env.num_envs, env.num_assets), dtype=torch.float64, device=dev)
+        # the f32 copy of the log-return table the first layer streams from (what states.float() would hold)
+        self._lr32 = getattr(env, "_log_return_f32", None)
+        if self._lr32 is None:
+            self._lr32 = env.log_return_environments.float().contiguous()
+        self.set_weights(W1, b1, W2, b2)
+        self.sync_from_env()
+
+    def set_weights(self, W1: torch.Tensor, b1: torch.Tensor, W2: torch.Tensor, b2: float) -> None:
+        W, H, dev = self.env.num_intervals, self.H, self.env._dev
+        w = W1.detach().to(dtype=torch.float32, device="cpu").reshape(W, 5, H)
+        self.w1t = w[:, :4, :].reshape(4 * W, H).t().contiguous().to(dev)
+        wpos = torch.zeros((H,), dtype=torch.float32)
+        for j in range(W):  # sequential f32 sum, j ascending: part of the contract (oracle: mlp_pack)
+            wpos = wpos + w[j, 4, :]
+        self.wpos = wpos.to(dev)
+        self.b1 = b1.detach().to(dtype=torch.float32, device=dev).reshape(H).contiguous()
+        self.w2 = W2.detach().to(dtype=torch.float32, device=dev).reshape(H).contiguous()
+        self.b2 = float(b2)
+
+    def sync_from_env(self) -> None:
+        from . import _lib
+
+        _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                                                 self.env._stream()))
+
+    def run(self, num_steps: int, record_actions: bool = True):
+        """Returns (actions (K, N, A) f32 or None, rewards (K, N) f64, dones (K, N) int32)."""
+        from . import _lib
+
+        env, K = self.env, int(num_steps)
+        N, A = env.num_envs, env.num_assets
+        actions = torch.empty((K, N, A), dtype=torch.float32, device=env._dev) if record_actions else None
+        rewards = torch.empty((K, N), dtype=torch.float64, device=env._dev)
+        dones = torch.empty((K, N), dtype=torch.int32, device=env._dev)
+        _lib.check(env._lib.fe_env_rollout_mlp(
+            env._handle, self._lr32.data_ptr(), self.w1t.data_ptr(), self.wpos.data_ptr(), self.b1.data_ptr(),
+            self.w2.data_ptr(), self.b2, self.H, self.act, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+            actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
+        return actions, rewards, dones
+
+    def observation(self) -> torch.Tensor:
+        """The (N, W, 5A) observation the next policy evaluation will see."""
+        from . import _lib
+
+        obs = self.env._next_obs()
+        _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                                               obs.data_ptr(), self.env._stream()))
+        return obs

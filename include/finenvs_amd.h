@@ -176,6 +176,25 @@ int fe_env_rollout_table(fe_env *env, const double *table, const double *wsum, d
                          int64_t *obs_src, double *obs_pos, float *actions_out, double *rewards_out,
                          int32_t *dones_out, void *stream);
 
+/*
+ * The same K-step loop with a two-layer perceptron head on the flattened window of every (env, asset) pair -- the
+ * shape of the reference's MLP networks (finenvs/agents/networks/multilayer_perceptron.py:17-25, default ELU) fed
+ * with states.float() (finenvs/agents/PPO/PPO_agent.py:101):
+ *   action = clamp(b2 + sum_h w2[h] * act(b1[h] + sum_{j<W} sum_{c<5} (float)obs[j][5a+c] * W1[5j+c][h]), -1, 1)
+ * The first layer is a dense (pairs x 5W x H) contraction and runs on the matrix cores (v_mfma_f32_32x32x2_f32:
+ * f32 in, f32 accumulate, exactly an fmaf chain); the summation order is part of the contract and restated by
+ * oracle/fe_oracle.c:fo_policy_mlp, so the pre-activations are bit-reproducible on the CPU:
+ *   logret_f32 (D, L, 4*A) f32 = (float) of the log-return table; w1t (H, 4W) f32 with w1t[h][4j+c] = W1[5j+c][h]
+ *   for the four log-return features; wpos (H) = sum_j W1[5j+4][h] (the position feature is the same in every
+ *   row); b1, w2 (H); H in {32, 64, 128}; activation 0 = ELU, 1 = ReLU, 2 = tanh.  W1t must fit the 160 KiB LDS
+ *   (H * (4W rounded up to a multiple of 32, + 4) * 4 bytes + a few KiB), else FE_ERR_ARG.
+ * Other arguments, loop semantics and side effects as fe_env_rollout_linear
+ * (examples/time_series/PPO_LSTM_training_SPY.py:22-28).
+ */
+int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, const float *wpos, const float *b1,
+                       const float *w2, float b2, int32_t H, int32_t activation, int32_t K, int64_t *obs_src,
+                       double *obs_pos, float *actions_out, double *rewards_out, int32_t *dones_out, void *stream);
+
 /* env_indices[env] = day (the host half of TSE:510-513 when redraw_mode == 0). */
 int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream);
 

@@ -518,3 +518,57 @@ void fo_policy_table_actions(const double *table, double wsum, double bias, cons
             actions_out[n * A + a] = (float)a64;
         }
 }
+
+/*
+ * f2, MLP head: CPU restatement of fe_env_rollout_mlp's policy on a materialised observation (N, W, 5A) f64.
+ * Two-layer perceptron on the flattened window of each (env, asset) pair, all in f32 (the reference's agents feed
+ * states.float() to their networks, PPO_agent.py:101; layer shape of multilayer_perceptron.py:17-25):
+ *   pre[h]  = fmaf chain, start fmaf((float)pos, wpos[h], b1[h]), then the 4W log-return features in the order
+ *             g = 0.. (two window rows per group, groups padded to a multiple of four), c = 0..3, row 2g before
+ *             row 2g+1  (rows past W contribute fmaf(0, 0, acc)) -- the k order of the v_mfma_f32_32x32x2_f32
+ *             chain of the HIP kernel;
+ *   action  = clamp(b2 + (P0 + P1), -1, 1), P_half = fmaf chain over the hidden units
+ *             32t + (r&3) + 8(r>>2) + 4*half, t and r ascending, of w2[h] * act(pre[h]).
+ * act: 0 ELU (alpha 1, expm1f), 1 ReLU (NaN passes), 2 tanh.  w1t is (H, 4W): w1t[h][4j+c] = W1[5j+c][h].
+ */
+static float fo_mlp_act(float z, int act) {
+    if (act == 1) return z > 0.0f ? z : (z != z ? z : 0.0f);
+    if (act == 2) return tanhf(z);
+    return z > 0.0f ? z : expm1f(z);
+}
+
+void fo_policy_mlp(const double *obs, const float *w1t, const float *wpos, const float *b1, const float *w2,
+                   float b2, int32_t H, int32_t act, int64_t N, int32_t W, int32_t A, float *actions_out,
+                   float *pre_out /* (N, A, H) or NULL */) {
+    const int K4 = 4 * W, ngroups = ((K4 + 7) / 8 + 3) / 4 * 4;
+    float *pre = (float *)malloc(sizeof(float) * (size_t)H);
+    for (int64_t n = 0; n < N; ++n)
+        for (int a = 0; a < A; ++a) {
+            const double *o = obs + (size_t)n * W * 5 * A + 5 * a;
+            const float pos32 = (float)o[4];
+            for (int h = 0; h < H; ++h) {
+                float acc = fmaf(pos32, wpos[h], b1[h]);
+                for (int g = 0; g < ngroups; ++g)
+                    for (int c = 0; c < 4; ++c)
+                        for (int half = 0; half < 2; ++half) {
+                            const int row = 2 * g + half;
+                            const float x = row < W ? (float)o[(size_t)row * 5 * A + c] : 0.0f;
+                            const float w = row < W ? w1t[(size_t)h * K4 + 4 * row + c] : 0.0f;
+                            acc = fmaf(w, x, acc);
+                        }
+                pre[h] = acc;
+                if (pre_out) pre_out[((size_t)n * A + a) * H + h] = acc;
+            }
+            float part[2] = {0.0f, 0.0f};
+            for (int half = 0; half < 2; ++half)
+                for (int t = 0; t < H / 32; ++t)
+                    for (int r = 0; r < 16; ++r) {
+                        const int h = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        part[half] = fmaf(w2[h], fo_mlp_act(pre[h], act), part[half]);
+                    }
+            float a32 = b2 + (part[0] + part[1]);
+            a32 = a32 < -1.0f ? -1.0f : (a32 > 1.0f ? 1.0f : a32);
+            actions_out[(size_t)n * A + a] = a32;
+        }
+    free(pre);
+}

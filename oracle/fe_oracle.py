@@ -149,6 +149,34 @@ def policy_linear(obs: np.ndarray, weights: np.ndarray, bias: float) -> np.ndarr
     return out
 
 
+def mlp_pack(W1: np.ndarray, W: int):
+    """(5W, H) first-layer weights (rows 5j+c, the flattened observation order) -> (w1t (H, 4W), wpos (H,)) as the
+    kernel takes them: log-return rows transposed, position rows summed over j in f32, j ascending."""
+    W1 = np.asarray(W1, dtype=np.float32).reshape(W, 5, -1)
+    w1t = np.ascontiguousarray(W1[:, :4, :].reshape(4 * W, -1).T)
+    wpos = np.zeros(W1.shape[2], dtype=np.float32)
+    for j in range(W):
+        wpos = (wpos + W1[j, 4, :]).astype(np.float32)
+    return w1t, wpos
+
+
+def policy_mlp(obs: np.ndarray, w1t: np.ndarray, wpos: np.ndarray, b1: np.ndarray, w2: np.ndarray, b2: float,
+               act: int = 0, return_pre: bool = False):
+    """Actions (N, A) f32 of the in-kernel MLP policy on a materialised observation (N, W, 5A)."""
+    obs = np.ascontiguousarray(obs, dtype=np.float64)
+    N, W, c5 = obs.shape
+    A = c5 // 5
+    w1t = np.ascontiguousarray(w1t, dtype=np.float32)
+    H = w1t.shape[0]
+    assert w1t.shape == (H, 4 * W)
+    wpos, b1, w2 = (np.ascontiguousarray(x, dtype=np.float32) for x in (wpos, b1, w2))
+    out = np.empty((N, A), dtype=np.float32)
+    pre = np.empty((N, A, H), dtype=np.float32) if return_pre else None
+    lib().fo_policy_mlp(_p(obs), _p(w1t), _p(wpos), _p(b1), _p(w2), C.c_float(b2), C.c_int32(H), C.c_int32(act),
+                        C.c_int64(N), C.c_int32(W), C.c_int32(A), _p(out), _p(pre))
+    return (out, pre) if return_pre else out
+
+
 def policy_table(LR: np.ndarray, weights: np.ndarray, W: int):
     """(table (D, L, A), wsum) of the table-form linear policy."""
     LR = np.ascontiguousarray(LR, dtype=np.float64)

@@ -1,27 +1,49 @@
-"""GPU box: throughput of the fused in-kernel-policy rollout (fe_env_rollout_linear) per config."""
-import os, sys
-import numpy as np, torch
+"""GPU box: throughput of the fused K-step rollouts (in-kernel policy, observation never written to HBM):
+linear window form, linear table form, MLP head on the matrix cores.
+
+    python tools/fused_bench.py <config> [form ...]      forms: window table mlp32 mlp64 mlp128
+"""
+import os
+import sys
+
+import torch
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import finenvs_amd
-from finenvs_amd.rollout import FusedLinearRollout
-from bench import CONFIGS, make_series
-for cfg in [int(x) for x in (sys.argv[1:] or ["2"])]:
-    name, N, A, W = CONFIGS[cfg]
-    prices, day_id, _ = make_series(A)
-    for eb in (None, 4, 8, 16, 32, 64, 128, 256):
-        if eb: os.environ["FE_TILE_ENVS"] = str(eb)
-        else: os.environ.pop("FE_TILE_ENVS", None)
+import finenvs_amd  # noqa: E402
+from bench import CONFIGS, make_series  # noqa: E402
+from finenvs_amd.rollout import FusedLinearRollout, FusedMLPRollout  # noqa: E402
+
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+forms = sys.argv[2:] or ["window", "table", "mlp32", "mlp64"]
+name, N, A, W = CONFIGS[cfg]
+prices, day_id, _ = make_series(A)
+K = int(os.environ.get("FUSED_K", "32"))
+tiles = [int(x) for x in os.environ.get("FUSED_TILES", "0").split(",")]
+g = torch.Generator().manual_seed(0)
+for form in forms:
+    for eb in tiles:
         env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", obs_buffers=1)
-        w = torch.randn((W, 5), dtype=torch.float64) * 2
-        roll = FusedLinearRollout(env, w, 0.0, form=os.environ.get('FUSED_FORM', 'window'))
-        K = int(os.environ.get('FUSED_K', '32'))
+        if eb:
+            env.set_launch(0, 0, eb)
+        if form.startswith("mlp"):
+            H = int(form[3:])
+            W1 = torch.randn((5 * W, H), generator=g) * (8.0 / W ** 0.5)
+            roll = FusedMLPRollout(env, W1, torch.randn(H, generator=g) * 0.3, torch.randn(H, generator=g) / H ** 0.5, 0.0)
+            flop = 2.0 * N * A * (4 * W) * H  # first layer, per step
+        else:
+            roll = FusedLinearRollout(env, torch.randn((W, 5), dtype=torch.float64, generator=g) * 2, 0.0, form=form)
+            flop = 0.0
         roll.run(K, record_actions=True)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize(); e0.record()
+        torch.cuda.synchronize()
+        e0.record()
         reps = 5
-        for _ in range(reps): roll.run(K, record_actions=True)
-        e1.record(); torch.cuda.synchronize()
+        for _ in range(reps):
+            roll.run(K, record_actions=True)
+        e1.record()
+        torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / (reps * K)
-        print(f"cfg {cfg} EB={env.launch_info()['tile_envs']:4d}: {ms*1e3:9.2f} us/step  {N/ms/1e6*1e3/1e3:8.2f} G env-steps/s", flush=True)
+        extra = f"  first layer {flop / ms / 1e9:7.1f} TFLOP/s f32 (peak 157)" if flop else ""
+        print(f"config {cfg} {form:7s} tile {eb or 'auto':>4}: {ms * 1e3:9.2f} us/step  {N / ms / 1e6:8.3f} G env-steps/s"
+              f"  {N * A / ms / 1e6:8.3f} G account-steps/s{extra}", flush=True)
         del env, roll
-        if A > 1 and eb and eb * A >= 256: break
