@@ -1729,12 +1729,42 @@ static int configure_launch(fe_env *env) {
     int64_t EB = (3 * cfg.N + 4 * resident) / (8 * resident);
     if (EB < 1) EB = 1;
     if (EB > cap) EB = cap;
+    int wgs_per_cu = 0;  // 0 = whatever the occupancy query allows
+#ifndef FE_GEOM_R01   /* experiment builds only: the round-1 geometry rule for every shape */
+#define FE_GEOM_R01 0
+#endif
+    if (A == 1 && !FE_GEOM_R01) {
+        // Single-asset envs (measured at 64k envs x W64 on a shared observation ring, tools/ab_step.py,
+        // profiles/r02_microbench/sweep{3,4}_c2.txt, sweep_f32_c2.txt).  A tile must be a whole number of workgroup
+        // iterations of phase 2 (4 wavefronts x one 5-KiB image = 512 f64 / 1024 f32 tuples): with f64 observations
+        // 8 envs of W = 64 run 31.2 us, 12 envs 35.2 us, 6 envs 42.2 us.  Fewer workgroups than the occupancy limit
+        // start faster (the dispatch ramp of 1792 workgroups costs up to 5 us of a 31 us launch): f64 observations
+        // are fastest with 4 workgroups per CU and ~8 short tiles each (31.2-31.8 us vs 33.0-34.2 us for the round-1
+        // geometry), f32 observations (half the bytes, a 17-19 us launch) with 6 per CU and 1-2 longer tiles each
+        // (17.4 us vs 19.4 us).
+        const int64_t wg_tuples = 4 * (kStageBytes / (5 * (cfg.obs_is_f32 ? 4 : 8)));
+        int64_t g = wg_tuples, w = cfg.W;
+        while (w) { const int64_t t = g % w; g = w; w = t; }  // gcd(wg_tuples, W)
+        const int64_t unit = wg_tuples / g;                  // envs per whole workgroup iteration
+        if (unit <= cap) {
+            wgs_per_cu = cfg.obs_is_f32 ? 6 : 4;
+            const int64_t res = (int64_t)env->cus * wgs_per_cu;
+            if (resident > res) resident = res;
+            // tiles per workgroup aimed at: 8 (f64) resp. 4/3 (f32)
+            const int64_t num = cfg.obs_is_f32 ? 3 * cfg.N : cfg.N, den = (cfg.obs_is_f32 ? 4 : 8) * resident * unit;
+            int64_t m = (num + den / 2) / den;
+            if (m < 1) m = 1;
+            EB = unit * m;
+            if (EB > cap) EB = cap - cap % unit;
+        }
+    }
     if (env->tile_override > 0) EB = env->tile_override < cap ? env->tile_override : cap;
     const int64_t num_tiles = (cfg.N + EB - 1) / EB;
     // the LDS footprint depends on EB: ask again with the real size before fixing the grid
     he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes((int)EB, A));
     if (he == hipSuccess && per_cu >= 1) {
         if (per_cu > 8) per_cu = 8;
+        if (wgs_per_cu > 0 && per_cu > wgs_per_cu) per_cu = wgs_per_cu;  // see above
         resident = (int64_t)env->cus * per_cu;
         if (resident > 8) resident -= resident % 8;
     }

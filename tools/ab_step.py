@@ -25,7 +25,9 @@ prices, day_id, _ = make_series(A)
 dev = "cuda:0"
 g = torch.Generator(device=dev).manual_seed(7)
 actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
-obs_bytes = N * W * 5 * A * 8
+F32 = os.environ.get("AB_F32") == "1"  # f32 observations
+OBS_DT = torch.float32 if F32 else torch.float64
+obs_bytes = N * W * 5 * A * (4 if F32 else 8)
 nbuf = 2 if 2 * obs_bytes < 200e9 else 1
 VAR = os.path.join(os.path.dirname(_lib.LIB_PATH), "variants")
 
@@ -34,7 +36,7 @@ def make(arm):
     nm, _, geo = arm.partition("=")
     lib = _lib.load() if nm == "product" else _lib.load(os.path.join(VAR, f"libfinenvs_amd.{nm}.so"))
     env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device",
-                                    seed=1234, obs_buffers=nbuf, _native=lib)
+                                    seed=1234, obs_buffers=nbuf, obs_dtype=OBS_DT, _native=lib)
     if geo:
         t, gr = (int(x) for x in geo.split(","))
         env.set_launch(t, gr)
@@ -67,7 +69,7 @@ SHARED_RING = None  # ONE observation ring for every arm: HBM write bandwidth de
 def block(env):
     global SHARED_RING
     if SHARED_RING is None:
-        SHARED_RING = ([torch.empty((N, W, 5 * A), dtype=torch.float64, device=dev) for _ in range(nbuf)]
+        SHARED_RING = ([torch.empty((N, W, 5 * A), dtype=OBS_DT, device=dev) for _ in range(nbuf)]
                        if not BIG else env._obs_ring)
     obs_b = [t.data_ptr() for t in (env._obs_ring if BIG else SHARED_RING)]
     rew = torch.empty((N,), dtype=torch.float64, device=dev)
