@@ -664,6 +664,10 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
 template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY>
 __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES_PER_EU - 1) void fe_env_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
+#if FE_STAMP
+    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();  // before any kernel argument is needed
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
     const TileLds l = carve_lds(smem + 4 * kStageBytes, EB, EB * A);
@@ -778,7 +782,10 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
         };
 #if FE_STAMP
         unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.stat_eval);
-        if (stamps && tid == 0) stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+        if (stamps && tid == 0) {
+            stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
+            stamps[blockIdx.x * 8 + 6] = t_entry;
+        }
 #endif
         bool act0, act1, act2;
         int64_t n_cur = env_of(tile, act0), n_nxt = env_of(tile + G, act1), n_nn;

@@ -38,7 +38,7 @@ for i in range(60):
         s = stamps.cpu().numpy().astype(np.float64) * 0.01  # 100 MHz ticks -> us
         t0 = s[:, 0].min()
         rows.append(np.stack([s[:, 0] - t0, s[:, 1] - s[:, 0], s[:, 2] - t0, s[:, 3] - t0, s[:, 4] - s[:, 0], s[:, 5] - s[:, 4],
-                              s[:, 1] - s[:, 5]], axis=1))
+                              s[:, 1] - s[:, 5], s[:, 6] - s[:, 6].min(), s[:, 0] - s[:, 6]], axis=1))
 r = np.median(np.stack(rows), axis=0)  # per workgroup, median over 20 launches
 
 
@@ -47,6 +47,8 @@ def q(x):
 
 
 print(f"config {cfg}: {name}; launch {env.launch_info()}; us relative to the launch's first workgroup start (median over 20 launches)")
+print("wavefront entry (abs)        ", q(r[:, 7]))
+print("   entry -> arguments loaded ", q(r[:, 8]))
 print("workgroup start              ", q(r[:, 0]))
 print("first tile: start->accounted ", q(r[:, 1]))
 print("   index+state+action loads  ", q(r[:, 4]))
@@ -56,3 +58,22 @@ print("first tile streamed (abs)    ", q(r[:, 2]))
 print("workgroup end (abs)          ", q(r[:, 3]))
 ends = np.sort(r[:, 3])
 print("last workgroup ends at %.2f us; 90 %% have ended by %.2f, 50 %% by %.2f" % (ends[-1], ends[int(0.9 * grid)], ends[grid // 2]))
+late = r[:, 7] > 0.5 * r[:, 7].max()
+print("late-starting workgroups: %d of %d; by blockIdx %% 8: %s; by blockIdx // (grid/8): %s" % (
+    late.sum(), grid, np.bincount(np.arange(grid)[late] % 8, minlength=8).tolist(),
+    np.bincount(np.arange(grid)[late] * 8 // grid, minlength=8).tolist()))
+lab = np.arange(grid) % 8
+print("per XCD label (blockIdx % 8): mean wavefront entry / mean workgroup end (us):")
+print("   " + "  ".join(f"{x}: {r[lab == x, 7].mean():5.2f} / {r[lab == x, 3].mean():5.2f}" for x in range(8)))
+# absolute time base of consecutive launches: does an XCD that ends early also start the NEXT launch early?
+# the same for the LAST of 20 back-to-back launches (no host synchronisation in between)
+rows2 = []
+for rep in range(10):
+    for i in range(20):
+        env.step(actions[i % 8])
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().astype(np.float64) * 0.01
+    rows2.append(np.stack([s[:, 6] - s[:, 6].min(), s[:, 3] - s[:, 6].min()], axis=1))
+r2 = np.median(np.stack(rows2), axis=0)
+print("back-to-back launches, per XCD label: mean wavefront entry / mean workgroup end (us):")
+print("   " + "  ".join(f"{x}: {r2[lab == x, 0].mean():5.2f} / {r2[lab == x, 1].mean():5.2f}" for x in range(8)))
