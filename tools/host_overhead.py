@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import finenvs_amd
 from bench import make_series
 prices, day_id, _ = make_series(1)
-env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=32, num_envs=1024, redraw="device")
+env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=32, num_envs=1024, redraw="device", obs_buffers=1)
 a = torch.zeros((1024, 1), device="cuda:0")
 env.reset()
 for _ in range(1000): env.step(a)
