@@ -62,6 +62,50 @@ def test_should_step_envs_1000_times(envs):
         assert bool(torch.isfinite(env.cash).all()) and int(env.env_spots.min()) >= 0
 
 
+def _write_reference_style_csv(path, inst, prices, day_id, second):
+    """A CSV in the row format of the reference's own fixture for `inst` (finenvs/data/README.md:7-9): IBM / OIH spell
+    MM/DD/YYYY,HH:MM, SPY spells YYYY-MM-DD,HH:MM:SS and carries pre-market rows from 04:00 (dropped by the 09:30-15:59
+    filter, TSE:90-91).  Prices are written with repr(): they parse back to the same doubles."""
+    import os
+
+    os.makedirs(os.path.dirname(path), exist_ok=True)
+    with open(path, "w") as f:
+        last = -1
+        for row, d, sec in zip(prices, day_id, second):
+            d, sec = int(d), int(sec)
+            date = f"2022-04-{1 + d:02d}" if inst == "SPY" else f"{1 + d // 28:02d}/{1 + d % 28:02d}/1998"
+            if inst == "SPY" and d != last:  # a few pre-market bars before each session
+                for k in range(3):
+                    f.write(f"{date},04:{k:02d}:00,1,1,1,1,100\n")
+                last = d
+            hh, mm, ss = sec // 3600, sec // 60 % 60, sec % 60
+            time = f"{hh:02d}:{mm:02d}:{ss:02d}" if inst == "SPY" else f"{hh:02d}:{mm:02d}"
+            f.write(f"{date},{time}," + ",".join(repr(float(x)) for x in row) + ",1000\n")
+
+
+@pytest.mark.parametrize("inst,fixture,kw", [("IBM", "tables_ibm.npz", {}), ("SPY", "tables_spy.npz", {}),
+                                             ("OIH", "tables_oih.npz", {"num_intervals": 32})])
+def test_reference_datasets_through_the_constructor_the_reference_test_uses(tmp_path, inst, fixture, kw):
+    """`TimeSeriesEnv("IBM", "dummy")` etc. as in the reference's unit test (tests/unit/test_time_series_env.py:10-14,
+    default num_intervals = 390, TSE:19), on the market-hours rows of the reference's own datasets (from the
+    fixtures: the files themselves do not travel) written back in each file's own date / time spelling: CSV ->
+    native reader -> bounds -> device tables must equal what the reference built, then 1000 steps as its test does."""
+    from finenvs_amd import TimeSeriesEnv
+
+    g = load_golden(fixture)
+    d = tmp_path / "data" / inst
+    _write_reference_style_csv(str(d / "dummy.csv"), inst, g["series_prices"], g["series_day_id"], g["series_second"])
+    env = TimeSeriesEnv(str(d), "dummy", **kw)
+    assert env.num_intervals == int(g["W"]) and env.num_envs == g["ref_price_environments"].shape[0] + 1
+    assert_bits(env.dataset.cpu().numpy(), g["ref_dataset"], "parsed market-hours frame")
+    assert_bits(env.price_environments.cpu().numpy(), g["ref_price_environments"], "price tables")
+    np.testing.assert_allclose(env.log_return_environments.cpu().numpy(), g["ref_log_return_environments"], rtol=1e-13, atol=1e-17)
+    assert isinstance(env.reset(), torch.Tensor)
+    for _ in range(1000):
+        step_helper(env)
+    assert bool(torch.isfinite(env.cash).all())
+
+
 def test_env_built_from_csv_equals_the_reference_tables(tmp_path):
     """End to end: CSV file -> native reader -> bounds -> device transform/tables, against what the
     reference built from the very same CSV (tests/golden/tables_ragged.npz)."""
