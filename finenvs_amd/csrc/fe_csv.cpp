@@ -161,6 +161,10 @@ int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_onl
     if (!m.ok) return fe_set_error(FE_ERR_ARG, "fe_csv_read: cannot open %s", path);
     std::unordered_map<uint64_t, int64_t> days;  // date key -> id in order of first appearance
     int64_t rows = 0, line_no = 0;
+    const char *prev_date = nullptr;
+    size_t prev_len = 0;
+    uint64_t prev_key = 0;
+    int64_t prev_id = 0;
     const char *p = m.p, *end = m.p + m.n;
     while (p < end) {
         const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
@@ -196,14 +200,23 @@ int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_onl
                 return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld: bad number in column %d", path, (long long)line_no, 3 + k);
             prices[rows * 4 + k] = v;
         }
-        const uint64_t key = (uint64_t)date_join_key(fb[0], fe_[0]);
-        auto it = days.find(key);
+        // rows of one date are consecutive in every real file: compare the date text with the previous row's first
+        uint64_t key;
         int64_t id;
-        if (it == days.end()) {
-            id = (int64_t)days.size();
-            days.emplace(key, id);
+        const size_t dlen = (size_t)(fe_[0] - fb[0]);
+        if (prev_date && dlen == prev_len && memcmp(prev_date, fb[0], dlen) == 0) {
+            key = prev_key;
+            id = prev_id;
         } else {
-            id = it->second;
+            key = (uint64_t)date_join_key(fb[0], fe_[0]);
+            auto it = days.find(key);
+            if (it == days.end()) {
+                id = (int64_t)days.size();
+                days.emplace(key, id);
+            } else {
+                id = it->second;
+            }
+            prev_date = fb[0]; prev_len = dlen; prev_key = key; prev_id = id;
         }
         day_id[rows] = id;
         if (date_key) date_key[rows] = (int64_t)key;
