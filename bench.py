@@ -6,7 +6,7 @@
 N > 1 is launched by the driver as
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 one rank per GPU; envs are sharded contiguously (weak scaling: every rank owns the
-config's full env count), no collective inside step(); once per TRAJ_T steps the
+config's full env count), no collective inside step(); once per chunk of `steps` steps the
 compact trajectory fields are all-gathered over RCCL.
 
 A "step" is one env.step(actions) over all envs of the workload: synthetic GBM minute
@@ -18,7 +18,7 @@ rollout loop keeps the previous observation alive while the next is written).
 The timed region is EXACTLY K steps between two (barrier + synchronize) fences; it is repeated
 R times and the MEDIAN block is reported (min / max beside it), because one K-step block at
 64k envs is under a millisecond.  With N > 1 there are two legs per workload: steps with the
-asynchronous trajectory all-gather (the headline `value`) and steps without it.
+asynchronous trajectory all-gather (the headline `value`; one whole gather per timed block) and steps without it.
 
 After the headline workload (BASELINE.json's "64k envs" configuration) the same process runs
 the larger BASELINE configs for a few steps each and reports them under "extra_configs" -- on
@@ -50,7 +50,8 @@ CONFIGS = {
     5: ("512k envs per GPU, 30 assets, window=128 (4M over 8 GPUs)", 524288, 30, 128),
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-TRAJ_T = 16             # steps per trajectory all-gather (N > 1 only)
+TRAJ_T = 16             # trajectory slots on one GPU (no exchange)
+TRAJ_BUDGET = 48e9      # bytes of trajectory chunks + gathered copies a rank may hold (N > 1)
 # the reference's own PyTorch-CPU path, measured in the build container
 REFERENCE_CPU_QUOTED = {"value": 40497, "unit": "env-steps/s", "cores": 8,
                         "what": "hmomin/FinEnvs TimeSeriesEnv.step, torch 2.10 CPU, 65536 envs x W64, build container"}
@@ -214,10 +215,17 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
         # Compact trajectory fields live in a device buffer; the step kernel writes rewards/dones
         # straight into slot t and the "policy" (the pre-generated action ring) owns the action slots,
-        # so storing a step costs nothing extra.  With N > 1 each full chunk is all-gathered (async).
-        traj = TrajectoryBuffer(TRAJ_T, N, A, device=dev)
-        for chunk in traj._views:  # ring period 8 divides TRAJ_T: slot t always holds ring[t % 8]
-            for t in range(TRAJ_T):
+        # so storing a step costs nothing extra.  With N > 1 a chunk is `steps` slots long (capped by memory), i.e.
+        # one timed block fills exactly one chunk, and the chunk filled by a block is all-gathered asynchronously
+        # at the first step of the NEXT block: every timed block contains one whole all-gather (issued at its
+        # start, drained by the fence at its end) that has the block's own steps to hide behind.
+        T = TRAJ_T
+        if world > 1:
+            per_step = N * (8 + 4 * A + 4)
+            T = max(1, min(steps, int(TRAJ_BUDGET // (per_step * (2 + 2 * world)))))
+        traj = TrajectoryBuffer(T, N, A, device=dev)
+        for chunk in traj._views:  # slot t of either chunk holds ring[t % 8] (any valid actions will do)
+            for t in range(T):
                 chunk[0][t].copy_(actions[t % 8])
         torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001  (allocation / construction: before any collective)
@@ -231,13 +239,13 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     gather = [world > 1]  # mutable: the timed legs flip it
 
     def one_step(i):
-        a, r, d = traj.next_slot()
-        obs, rew, done, _ = env.step(a, rewards_out=r, dones_out=d)
-        if traj.full():
+        if traj.full():  # checked at the START of a step: a chunk completed by a block goes out with the next block
             if gather[0]:
-                traj.all_gather_async()  # overlaps the next TRAJ_T steps; waited for before reuse
+                traj.all_gather_async()  # overlaps the following steps; waited for before its chunk is reused
             else:
                 traj.clear()
+        a, r, d = traj.next_slot()
+        obs, rew, done, _ = env.step(a, rewards_out=r, dones_out=d)
         return obs
 
     roll = None
@@ -279,7 +287,9 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     legs = {}
     if world > 1:
         gather[0] = True
-        run_steps(TRAJ_T)  # one chunk in flight before the timed blocks
+        fence()
+        traj.clear()
+        run_steps(T)  # one full chunk: the first timed block has something to gather
         legs["with_all_gather"] = timed_blocks(R)
         fence()
         gather[0] = False
@@ -351,7 +361,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     if world > 1:
         res["multi_gpu"] = {
             "ranks_seen": D.dist.get_world_size(), "collective_backend": D.backend,
-            "trajectory_slots": TRAJ_T, "all_gather_every_steps": TRAJ_T,
+            "trajectory_slots": T, "all_gather_every_steps": T,
+            "all_gather_issue": "asynchronous, at the first step after a chunk is full; drained inside the timed block",
             "packed_bytes_per_rank_per_chunk": traj._nbytes,
             "gathered_bytes_per_rank_per_chunk": traj._nbytes * world,
             "value_with_all_gather": res["repeats"]["with_all_gather"]["value_median"],
