@@ -80,8 +80,7 @@ constexpr int kBlock = 256;
 //   bit 3  phase 1 without its global stores (state write-back, reward, done)
 //   bit 4  phase 1 without its global loads (constants instead)
 //   bit 5  phase 1 without the accounting arithmetic
-//   bit 6  no phase 1 (nor its loads) for a workgroup's FIRST tile only   (is it the start-up chain?)
-//   bit 7  no phase 1 (nor its loads) for all tiles BUT the first         (or the per-tile bubbles?)
+//   (bits 6 / 7 -- phase 1 skipped on the first tile only / on all but the first -- were used once and removed)
 #ifndef FE_ABLATE
 #define FE_ABLATE 0
 #endif
@@ -91,6 +90,14 @@ constexpr int kBlock = 256;
 #ifndef FE_STAMP
 #define FE_STAMP 0
 #endif
+// 1 (default): the single-asset f64 step kernel issues the first tile's table loads before its accounting
+// (0 = A/B arm).  Measured on a shared ring (profiles/r02_microbench/ab_hoist.txt): 30.57 -> 29.32 us at config 2.
+// Not for f32 observations: they run 6 workgroups per CU (80 VGPRs) and the 16 extra live registers spill.
+#ifndef FE_HOIST_FIRST
+#define FE_HOIST_FIRST 1
+#endif
+template <typename OT>
+constexpr bool kHoistFirst = FE_HOIST_FIRST != 0 && sizeof(OT) == 8;
 
 thread_local char g_err[512] = "";
 
@@ -563,43 +570,92 @@ __device__ __forceinline__ void describe_tile(const Params &p, const TileLds &l,
     }
 }
 
-// Phase 2 for one tile: l.src / l.pos -> (ebt, W, 5A) observation at dst, through this wavefront's
-// private LDS image.  No workgroup barrier inside.
+template <typename OT>
+using TupleOf = typename std::conditional<sizeof(OT) == 4, float4, double4>::type;
+template <typename OT>
+constexpr int kTuplesPerIter = kStageBytes / (5 * (int)sizeof(OT));  // tuples one wavefront turns per iteration
+
+// Table tuples of one phase-2 iteration held across other work: named members, passed by value -- an array that is
+// selected against a freshly loaded one ends up in scratch memory behind flat loads (measured: 31 -> 42 us).
+template <typename OT>
+struct PreTuples {
+    TupleOf<OT> v0, v1, v2, v3;  // G = 2 (f64) uses v0, v1; G = 4 (f32) all four
+};
+
+// The table loads of one phase-2 iteration of one wavefront (they need l.src only, not the position feature).
+template <typename OT, bool SINGLE>
+__device__ __forceinline__ void stream_load(const Params &p, const TileLds &l, int A, uint32_t tuples, uint32_t base,
+                                            int lane, TupleOf<OT> (&v)[kTuplesPerIter<OT> / 64], bool skip = false) {
+    constexpr int G = kTuplesPerIter<OT> / 64;
+    const uint32_t WA = (uint32_t)p.W * (uint32_t)A;
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) v[gi] = TupleOf<OT>{};
+    if (skip) return;
+    // f32 observations read a pre-cast f32 copy of the table when one is bound: half the L2 traffic,
+    // same values ((float) of the f64 entry either way)
+    const bool narrow = sizeof(OT) == 4 && p.LR32 != nullptr;
+#pragma unroll
+    for (int gi = 0; gi < G; ++gi) {
+        const uint32_t t = base + gi * 64 + lane;
+        const uint32_t tc = t < tuples ? t : tuples - 1;  // tail lanes re-read the last tuple
+        const uint32_t ee = fdiv(tc, p.div_WA);           // env within the tile
+        const uint32_t r = tc - ee * WA;                  // (row j, asset a) = r / A, r % A
+#if FE_ABLATE & 2
+        v[gi].x = (decltype(v[gi].x))tc; v[gi].y = v[gi].x; v[gi].z = v[gi].x; v[gi].w = v[gi].x;
+        if (false)
+#endif
+        if constexpr (sizeof(OT) == 4) {
+            if (narrow) {
+                v[gi] = *reinterpret_cast<const float4 *>(p.LR32 + l.src[ee] + 4u * r);
+            } else {
+                const double4 d = *reinterpret_cast<const double4 *>(p.LR + l.src[ee] + 4u * r);
+                v[gi] = make_float4((float)d.x, (float)d.y, (float)d.z, (float)d.w);
+            }
+        } else {
+            v[gi] = *reinterpret_cast<const double4 *>(p.LR + l.src[ee] + 4u * r);
+        }
+    }
+}
+
+template <typename OT, int VEC, bool SINGLE>
+__device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, OT *stage, int A, int ebt, OT *dst,
+                                            int lane, int wave, int nwaves, bool use_pre, PreTuples<OT> pre);
 template <typename OT, int VEC, bool SINGLE>
 __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, OT *stage, int A, int ebt, OT *dst,
                                             int lane, int wave, int nwaves = kBlock / 64) {
-    constexpr int TPI = kStageBytes / (5 * (int)sizeof(OT));  // tuples per wave iteration
-    constexpr int G = TPI / 64;                                // tuples per lane per iteration
+    stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt, dst, lane, wave, nwaves, false, PreTuples<OT>{});
+}
+
+// Phase 2 for one tile: l.src / l.pos -> (ebt, W, 5A) observation at dst, through this wavefront's
+// private LDS image.  No workgroup barrier inside.  `pre` (optional): the table tuples of this wavefront's FIRST
+// iteration, loaded earlier by stream_load (the start-up chain of a workgroup's first tile).
+template <typename OT, int VEC, bool SINGLE>
+__device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, OT *stage, int A, int ebt, OT *dst,
+                                            int lane, int wave, int nwaves, bool use_pre, PreTuples<OT> pre) {
+    constexpr int TPI = kTuplesPerIter<OT>;  // tuples per wave iteration
+    constexpr int G = TPI / 64;              // tuples per lane per iteration
     const uint32_t WA = (uint32_t)p.W * (uint32_t)A;           // 32-byte table tuples per env
     const uint32_t tuples = (uint32_t)ebt * WA;
     for (uint32_t base = wave * TPI; base < tuples; base += nwaves * TPI) {
-        // f32 observations read a pre-cast f32 copy of the table when one is bound: half the L2 traffic,
-        // same values ((float) of the f64 entry either way)
-        using TupleT = typename std::conditional<sizeof(OT) == 4, float4, double4>::type;
-        const bool narrow = sizeof(OT) == 4 && p.LR32 != nullptr;
+        using TupleT = TupleOf<OT>;
         TupleT v[G];
         double pz[G];
+        stream_load<OT, SINGLE>(p, l, A, tuples, base, lane, v, /*skip=*/use_pre && base == (uint32_t)wave * TPI);
+        if (use_pre && base == (uint32_t)wave * TPI) {
+            v[0] = pre.v0;
+            v[1] = pre.v1;
+            if constexpr (G == 4) {
+                v[2] = pre.v2;
+                v[3] = pre.v3;
+            }
+        }
 #pragma unroll
         for (int gi = 0; gi < G; ++gi) {
             const uint32_t t = base + gi * 64 + lane;
-            const uint32_t tc = t < tuples ? t : tuples - 1;  // tail lanes re-read the last tuple
-            const uint32_t ee = fdiv(tc, p.div_WA);           // env within the tile
-            const uint32_t r = tc - ee * WA;                  // (row j, asset a) = r / A, r % A
+            const uint32_t tc = t < tuples ? t : tuples - 1;
+            const uint32_t ee = fdiv(tc, p.div_WA);
+            const uint32_t r = tc - ee * WA;
             const uint32_t aa = SINGLE ? 0u : r - fdiv(r, p.div_A) * (uint32_t)A;
-#if FE_ABLATE & 2
-            v[gi].x = (decltype(v[gi].x))tc; v[gi].y = v[gi].x; v[gi].z = v[gi].x; v[gi].w = v[gi].x;
-            if (false)
-#endif
-            if constexpr (sizeof(OT) == 4) {
-                if (narrow) {
-                    v[gi] = *reinterpret_cast<const float4 *>(p.LR32 + l.src[ee] + 4u * r);
-                } else {
-                    const double4 d = *reinterpret_cast<const double4 *>(p.LR + l.src[ee] + 4u * r);
-                    v[gi] = make_float4((float)d.x, (float)d.y, (float)d.z, (float)d.w);
-                }
-            } else {
-                v[gi] = *reinterpret_cast<const double4 *>(p.LR + l.src[ee] + 4u * r);
-            }
             pz[gi] = l.pos[ee * A + aa];
         }
 #if FE_ABLATE & 4
@@ -661,8 +717,63 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
     }
 }
 
+// Software pipeline state of the single-asset step kernel: inputs of the current tile, prefetched inputs of the
+// next one, indices of the one after.
+struct PipeState {
+    SleeveIn in_cur, in_nxt;
+    float action_cur, action_nxt;
+    int64_t n_cur, n_nxt, n_nn, idx1, spot1, idx2, spot2;
+    bool act0, act1, act2;
+    unsigned long long t_accounted;  // FE_STAMP builds
+};
+
+__device__ __forceinline__ int64_t pipe_env_of(const Params &p, int EB, int e, int64_t t, bool &act) {
+    const int64_t n0 = t * EB;
+    const int64_t left = p.N - n0;
+    act = t < p.num_tiles && (int64_t)e < (left < (int64_t)EB ? left : (int64_t)EB);
+    return n0 + e;
+}
+
+// One tile of the single-asset pipeline: account it (inputs already in registers), prefetch the next tile's body and
+// the head of the one after, stream its observation.  FIRST: the workgroup's first tile, whose first phase-2
+// iteration may use table tuples loaded before the accounting (`pre`).
+template <typename OT, int VEC, bool FIRST>
+__device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, OT *stage, PipeState &ps, int64_t tile,
+                                            int64_t G, int EB, int e, int lane, int wave, PreTuples<OT> pre) {
+    const int64_t n0 = tile * EB;
+    const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+    account_core<true>(p, l, 1, e, 0, ps.act0, ps.n_cur, ps.n_cur, ps.in_cur, ps.action_cur, p.rew, p.done);
+    tile_barrier();
+#if FE_STAMP
+    if (FIRST) ps.t_accounted = __builtin_amdgcn_s_memrealtime();
+#endif
+    // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
+    load_body(p, 1, 0, ps.act1, ps.n_nxt, ps.idx1, ps.spot1, ps.in_nxt);
+    if (ps.act1) ps.action_nxt = p.actions[ps.n_nxt];
+    ps.n_nn = pipe_env_of(p, EB, e, tile + 2 * G, ps.act2);
+    load_head(p, ps.act2, ps.n_nn, ps.idx2, ps.spot2);
+    stream_tile<OT, VEC, true>(p, l, stage, 1, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave,
+                               kBlock / 64, FIRST && kHoistFirst<OT>, pre);
+    tile_barrier();  // LDS is reused by the next tile
+    ps.in_cur = ps.in_nxt;
+    ps.action_cur = ps.action_nxt;
+    ps.n_cur = ps.n_nxt; ps.act0 = ps.act1;
+    ps.n_nxt = ps.n_nn; ps.act1 = ps.act2;
+    ps.idx1 = ps.idx2; ps.spot1 = ps.spot2;
+}
+
+// Wavefronts per SIMD the kernels are built for = workgroups per CU they are launched with (configure_launch): the
+// single-asset step kernel runs 4 per CU with f64 observations (128 VGPRs: room for the hoisted first-iteration
+// tuples) and 6 with f32 (80 VGPRs: no more spills -- at 7 / 72 VGPRs it spilled 28 bytes per lane); reset / render
+// and the multi-asset kernels keep round 1's 7 and 6.
+#ifndef FE_F32_WAVES
+#define FE_F32_WAVES 6
+#endif
+template <typename OT, bool SINGLE, bool RESET_ONLY>
+constexpr int kEnvKernelWaves = !SINGLE ? FE_MIN_WAVES_PER_EU - 1
+                                : (RESET_ONLY ? FE_MIN_WAVES_PER_EU : (sizeof(OT) == 8 ? (kHoistFirst<OT> ? 4 : FE_MIN_WAVES_PER_EU) : FE_F32_WAVES));
 template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY>
-__global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES_PER_EU - 1) void fe_env_kernel(const Params p) {
+__global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) void fe_env_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
 #if FE_STAMP
     const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();  // before any kernel argument is needed
@@ -774,12 +885,6 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
         // memory round trips.
         const int64_t G = gridDim.x;
         int64_t tile = blockIdx.x;
-        auto env_of = [&](int64_t t, bool &act) {
-            const int64_t n0 = t * EB;
-            const int64_t left = p.N - n0;
-            act = t < p.num_tiles && (int64_t)e < (left < (int64_t)EB ? left : (int64_t)EB);
-            return n0 + e;
-        };
 #if FE_STAMP
         unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.stat_eval);
         if (stamps && tid == 0) {
@@ -787,89 +892,60 @@ __global__ __launch_bounds__(kBlock, SINGLE ? FE_MIN_WAVES_PER_EU : FE_MIN_WAVES
             stamps[blockIdx.x * 8 + 6] = t_entry;
         }
 #endif
-        bool act0, act1, act2;
-        int64_t n_cur = env_of(tile, act0), n_nxt = env_of(tile + G, act1), n_nn;
-        int64_t idx1, spot1, idx2, spot2;
-        SleeveIn in_cur, in_nxt;
-        float action_cur = 0.0f, action_nxt = 0.0f;
-#if FE_ABLATE & (64 | 128)
-        const bool skip_first = (FE_ABLATE & 64) != 0, skip_rest = (FE_ABLATE & 128) != 0;
-        auto fake = [&](int64_t t) {
-            const int64_t n0f = t * EB;
-            if (n0f + e < p.N && e < EB) {
-                l.src[e] = (((n0f + e) % p.D) * p.L + 1) * 4;
-                l.pos[e] = (double)e;
-            }
-        };
-        if (!skip_first) {
-#endif
+        PipeState ps;
+        ps.action_cur = 0.0f; ps.action_nxt = 0.0f;
+        ps.n_cur = pipe_env_of(p, EB, e, tile, ps.act0);
+        ps.n_nxt = pipe_env_of(p, EB, e, tile + G, ps.act1);
         // first tile: everything that needs no index goes out with the index loads (one round trip), only the
         // bar gather (an L2 hit) waits for them
-        load_head(p, act0, n_cur, idx1, spot1);
-        load_state(p, act0, n_cur * A + a, in_cur);
-        if (act0) action_cur = p.actions[n_cur * A + a];
+        load_head(p, ps.act0, ps.n_cur, ps.idx1, ps.spot1);
+        load_state(p, ps.act0, ps.n_cur, ps.in_cur);
+        if (ps.act0) ps.action_cur = p.actions[ps.n_cur];
 #if FE_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (stamps && tid == 0) stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
 #endif
-        load_bar(p, A, a, act0, idx1, spot1, in_cur);
+        load_bar(p, 1, 0, ps.act0, ps.idx1, ps.spot1, ps.in_cur);
+        PreTuples<OT> pre{};  // table tuples of this wavefront's first phase-2 iteration (FE_HOIST_FIRST)
+        // Start-up chain of the first tile: the window descriptors need the index loads only, so they are published
+        // now and every wavefront issues the table loads of its first phase-2 iteration BEFORE the accounting --
+        // one L2/MALL round trip less between kernel entry and the first observation store.
+        if constexpr (kHoistFirst<OT>) {
+            if (ps.act0) {
+                const int64_t s0 = ps.spot1 + 1;
+                const int64_t s0c = s0 + p.W <= p.L ? s0 : p.L - p.W;
+                l.src[e] = (ps.idx1 * p.L + s0c) * 4;  // A == 1
+            }
+            tile_barrier();
+            const int64_t left0 = p.N - tile * EB;
+            const uint32_t tuples0 = (uint32_t)(left0 < (int64_t)EB ? left0 : (int64_t)EB) * (uint32_t)p.W;
+            if ((uint32_t)wave * kTuplesPerIter<OT> < tuples0 && tile < p.num_tiles) {
+                TupleOf<OT> v0[kTuplesPerIter<OT> / 64];
+                stream_load<OT, true>(p, l, 1, tuples0, (uint32_t)wave * kTuplesPerIter<OT>, lane, v0);
+                pre.v0 = v0[0];
+                pre.v1 = v0[1];
+                if constexpr (kTuplesPerIter<OT> / 64 == 4) {
+                    pre.v2 = v0[2];
+                    pre.v3 = v0[3];
+                }
+            }
+        }
 #if FE_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (stamps && tid == 0) stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
 #endif
-#if FE_ABLATE & (64 | 128)
-        }
-        if (!skip_rest)
-#endif
-        load_head(p, act1, n_nxt, idx1, spot1);
-        for (; tile < p.num_tiles; tile += G) {
-            const int64_t n0 = tile * EB;
-            const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
-#if FE_ABLATE & (64 | 128)
-            const bool first = tile == (int64_t)blockIdx.x;
-            if (first ? skip_first : skip_rest) {
-                fake(tile);
-                tile_barrier();
-                if (first && !skip_rest) {  // the pipeline's prefetches for tile 2 still have to be issued
-                    load_body(p, A, a, act1, n_nxt * A + a, idx1, spot1, in_nxt);
-                    if (act1) action_nxt = p.actions[n_nxt * A + a];
-                    n_nn = env_of(tile + 2 * G, act2);
-                    load_head(p, act2, n_nn, idx2, spot2);
-                }
-                stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
-                tile_barrier();
-                in_cur = in_nxt; action_cur = action_nxt; n_cur = n_nxt; act0 = act1; n_nxt = n_nn; act1 = act2; idx1 = idx2; spot1 = spot2;
-                continue;
+        load_head(p, ps.act1, ps.n_nxt, ps.idx1, ps.spot1);
+        // one tile per call; the workgroup's first tile is peeled (FIRST) so that `pre` dies before the loop
+        if (tile < p.num_tiles) {
+            single_tile<OT, VEC, true>(p, l, stage, ps, tile, G, EB, e, lane, wave, pre);
+#if FE_STAMP
+            if (stamps && tid == 0) {
+                stamps[blockIdx.x * 8 + 1] = ps.t_accounted;
+                stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             }
 #endif
-            account_core<SINGLE>(p, l, A, e, a, act0, n_cur, n_cur * A + a, in_cur, action_cur, p.rew, p.done);
-            if constexpr (SINGLE) tile_barrier();
-#if FE_STAMP
-            if (stamps && tid == 0 && tile == (int64_t)blockIdx.x) stamps[blockIdx.x * 8 + 1] = __builtin_amdgcn_s_memrealtime();
-#endif
-            // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
-#if FE_ABLATE & 128
-            if (false) {
-#endif
-            load_body(p, A, a, act1, n_nxt * A + a, idx1, spot1, in_nxt);
-            if (act1) action_nxt = p.actions[n_nxt * A + a];
-            n_nn = env_of(tile + 2 * G, act2);
-            load_head(p, act2, n_nn, idx2, spot2);
-#if FE_ABLATE & 128
-            }
-            n_nn = env_of(tile + 2 * G, act2);
-#endif
-            stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
-                                         reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
-            tile_barrier();  // LDS is reused by the next tile
-#if FE_STAMP
-            if (stamps && tid == 0 && tile == (int64_t)blockIdx.x) stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-#endif
-            in_cur = in_nxt;
-            action_cur = action_nxt;
-            n_cur = n_nxt; act0 = act1;
-            n_nxt = n_nn; act1 = act2;
-            idx1 = idx2; spot1 = spot2;
+            for (tile += G; tile < p.num_tiles; tile += G)
+                single_tile<OT, VEC, false>(p, l, stage, ps, tile, G, EB, e, lane, wave, PreTuples<OT>{});
         }
 #if FE_STAMP
         if (stamps && tid == 0) {
