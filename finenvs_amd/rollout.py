@@ -73,7 +73,30 @@ class GraphedRollout:
         return self.obs
 
 
-class FusedLinearRollout:
+class _FusedEvaluation:
+    """Shared by the fused rollouts: the reference's evaluation loop on the device."""
+
+    def evaluate_returns(self, chunk: int = 64, max_steps: int = 1_000_000) -> torch.Tensor:
+        """The reference's evaluation loop (examples/time_series/PPO_LSTM_testing_SPY.py:43-52): step the
+        evaluate-mode env with the actor until ``info["returns"]`` would appear, i.e. every env has finished one
+        episode; returns those per-env episode returns.  Runs ``chunk`` steps per launch; steps past an env's
+        termination cannot change its return (TSE:526-528 zeroes their rewards).  (The reference feeds the actor's
+        output unclamped; the env's share-change clamp, TSE:298-302, makes that equal to the clamped action.)"""
+        env = self.env
+        if not env.evaluate:
+            raise ValueError("evaluate_returns needs an env constructed with evaluate=True")
+        steps = 0
+        while steps < max_steps:
+            self.run(chunk, record_actions=False)
+            steps += chunk
+            if int(env._counters[0].item()) == env.num_envs:
+                returns = env.episode_returns.clone()
+                env.reset_evaluation_metrics()
+                return returns
+        raise RuntimeError("episodes did not all terminate within max_steps")
+
+
+class FusedLinearRollout(_FusedEvaluation):
     """K env steps per launch with an in-kernel linear policy (SURVEY.md 8f.2, C ABI
     ``fe_env_rollout_linear``): the whole loop
 
@@ -151,24 +174,6 @@ class FusedLinearRollout:
                 actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
         return actions, rewards, dones
 
-    def evaluate_returns(self, chunk: int = 64, max_steps: int = 1_000_000) -> torch.Tensor:
-        """The reference's evaluation loop (examples/time_series/PPO_LSTM_testing_SPY.py:43-52): step the
-        evaluate-mode env until ``info["returns"]`` would appear, i.e. every env has finished one episode;
-        returns those per-env episode returns.  Runs ``chunk`` steps per launch; steps past an env's
-        termination cannot change its return (TSE:526-528 zeroes their rewards)."""
-        env = self.env
-        if not env.evaluate:
-            raise ValueError("evaluate_returns needs an env constructed with evaluate=True")
-        steps = 0
-        while steps < max_steps:
-            self.run(chunk, record_actions=False)
-            steps += chunk
-            if int(env._counters[0].item()) == env.num_envs:
-                returns = env.episode_returns.clone()
-                env.reset_evaluation_metrics()
-                return returns
-        raise RuntimeError("episodes did not all terminate within max_steps")
-
     def observation(self) -> torch.Tensor:
         """The (N, W, 5A) observation the next policy evaluation will see."""
         from . import _lib
@@ -179,7 +184,7 @@ class FusedLinearRollout:
         return obs
 
 
-class FusedMLPRollout:
+class FusedMLPRollout(_FusedEvaluation):
     """K env steps per launch with an in-kernel two-layer perceptron policy on the flattened observation window of
     every (env, asset) pair (SURVEY.md 8f.2 "linear/MLP head"; C ABI ``fe_env_rollout_mlp``):
 

@@ -178,3 +178,28 @@ def test_mlp_rollout_argument_errors(fe, fo):
     roll = FusedMLPRollout(big, torch.zeros((5 * 390, 128)), torch.zeros(128), torch.zeros(128))
     with pytest.raises(FinEnvsNativeError, match="LDS"):
         roll.run(1)
+
+
+def test_mlp_evaluation_loop_returns_match_stepwise_oracle(fe, fo):
+    """FusedMLPRollout.evaluate_returns = the reference's evaluation loop (PPO_LSTM_testing_SPY.py:43-52) with an MLP
+    actor, K steps per launch: the per-env episode returns equal the oracle stepped one action at a time (ReLU head:
+    bit for bit)."""
+    from finenvs_amd.rollout import FusedMLPRollout
+
+    N, A, W, H = 90, 2, 8, 32
+    ref, env = _make(fe, fo, N, A, W, 6, 40, 0.1, True, seed=5)
+    W1, b1, W2, b2 = _weights(W, H, seed=2)
+    w1t, wpos = fo.mlp_pack(W1, W)
+    roll = FusedMLPRollout(env, torch.from_numpy(W1), torch.from_numpy(b1), torch.from_numpy(W2), float(b2), activation="relu")
+    got = t2n(roll.evaluate_returns(chunk=16))
+    ref.auto_emit = True
+    obs = ref.reset().copy()
+    want = None
+    for _ in range(2000):
+        obs, _, _, info = ref.step(fo.policy_mlp(obs, w1t, wpos, b1, W2, b2, act=1))
+        obs = obs.copy()
+        if "returns" in info:
+            want = info["returns"]
+            break
+    assert want is not None
+    assert_bits(got, want, "episode returns")
