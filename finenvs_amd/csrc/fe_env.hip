@@ -96,8 +96,11 @@ constexpr int kBlock = 256;
 #ifndef FE_HOIST_FIRST
 #define FE_HOIST_FIRST 1
 #endif
+#ifndef FE_F32_WAVES
+#define FE_F32_WAVES 6
+#endif
 template <typename OT>
-constexpr bool kHoistFirst = FE_HOIST_FIRST != 0 && sizeof(OT) == 8;
+constexpr bool kHoistFirst = FE_HOIST_FIRST != 0 && (sizeof(OT) == 8 || FE_F32_WAVES <= 5);
 
 thread_local char g_err[512] = "";
 
@@ -766,9 +769,6 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
 // single-asset step kernel runs 4 per CU with f64 observations (128 VGPRs: room for the hoisted first-iteration
 // tuples) and 6 with f32 (80 VGPRs: no more spills -- at 7 / 72 VGPRs it spilled 28 bytes per lane); reset / render
 // and the multi-asset kernels keep round 1's 7 and 6.
-#ifndef FE_F32_WAVES
-#define FE_F32_WAVES 6
-#endif
 template <typename OT, bool SINGLE, bool RESET_ONLY>
 constexpr int kEnvKernelWaves = !SINGLE ? FE_MIN_WAVES_PER_EU - 1
                                 : (RESET_ONLY ? FE_MIN_WAVES_PER_EU : (sizeof(OT) == 8 ? (kHoistFirst<OT> ? 4 : FE_MIN_WAVES_PER_EU) : FE_F32_WAVES));
@@ -1830,7 +1830,7 @@ static int configure_launch(fe_env *env) {
         while (w) { const int64_t t = g % w; g = w; w = t; }  // gcd(wg_tuples, W)
         const int64_t unit = wg_tuples / g;                  // envs per whole workgroup iteration
         if (unit <= cap) {
-            wgs_per_cu = cfg.obs_is_f32 ? 6 : 4;
+            wgs_per_cu = cfg.obs_is_f32 ? (FE_F32_WAVES < 6 ? FE_F32_WAVES : 6) : 4;
             const int64_t res = (int64_t)env->cus * wgs_per_cu;
             if (resident > res) resident = res;
             // tiles per workgroup aimed at: 8 (f64) resp. 4/3 (f32)
