@@ -17,7 +17,7 @@ import csv, glob, collections
 agg = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "fe_env_kernel" in r["Kernel_Name"] and "false>" in r["Kernel_Name"].split("(")[0][-8:]:
+        if "fe_env_kernel" in r["Kernel_Name"] and ", false>" in r["Kernel_Name"]:  # the step kernel (RESET_ONLY = false)
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print(f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
