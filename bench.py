@@ -119,9 +119,9 @@ def cpu_baseline(A: int, W: int, budget_s: float = 12.0):
 
 
 def pmc_traffic(config: int, f32: bool):
-    """HBM traffic per launch from the committed PMC passes (profiles/hbm_traffic.json): rocprofv3 cannot
-    collect counters from inside this process, so the figure comes from the profiling run named in
-    `traffic_source` (same binary, same command line; tools/profile_box.sh)."""
+    """Fallback for roofline.traffic when the live counter passes (live_pmc_traffic) are unavailable or switched
+    off: HBM traffic per launch from the committed PMC passes (profiles/hbm_traffic.json), with the profiling run
+    named in `traffic_source` (tools/profile_box.sh)."""
     path = os.path.join(REPO, "profiles", "hbm_traffic.json")
     key = f"config{config}" + ("_f32" if f32 else "")
     try:
@@ -131,6 +131,69 @@ def pmc_traffic(config: int, f32: bool):
     if not ent:
         return None, None
     return ent.get("bytes_per_launch"), f"profiles/hbm_traffic.json[{key}], run tag {ent.get('tag')} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
+
+
+def live_pmc_traffic(config: int, f32: bool, redraw: str):
+    """HBM traffic per launch MEASURED IN THIS RUN: two child processes of this very script (`--pmc-child`: the same
+    workload, 16 launches) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, as
+    MI355X_MICROARCH.md's HBM section prescribes; both counters are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B
+    requests at 64 B).  Returns (bytes per launch, description) or (None, reason)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(exe):
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="fe_pmc_", dir="/tmp")
+    vals = {}
+    try:
+        for kind in ("FETCH_SIZE", "WRITE_SIZE"):
+            cmd = [exe, "--pmc", kind, "--output-format", "csv", "-d", os.path.join(out, kind), "--",
+                   sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(config), "--redraw", redraw]
+            if f32:
+                cmd.append("--obs-f32")
+            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+                               stderr=subprocess.DEVNULL, timeout=240)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {kind} child exited with {r.returncode}"
+            rows = []
+            for f in glob.glob(os.path.join(out, kind, "*", "*_counter_collection.csv")):
+                for row in csv.DictReader(open(f)):
+                    if "fe_env_kernel" in row["Kernel_Name"] and ", false>" in row["Kernel_Name"] and row["Counter_Name"] == kind:
+                        rows.append(float(row["Counter_Value"]))
+            if len(rows) < 8:
+                return None, f"no {kind} rows for the step kernel"
+            rows = rows[len(rows) // 4:]  # drop the warm-up launches
+            vals[kind] = (sum(rows) / len(rows), len(rows))
+    except Exception as exc:  # noqa: BLE001
+        return None, f"{type(exc).__name__}: {exc}"
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
+    return traffic, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of bench.py "
+                     f"({vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} launches averaged; 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)")
+
+
+def pmc_child(args):
+    """`--pmc-child`: the headline workload's step kernel, a few launches, nothing else (what the rocprofv3 counter
+    passes of live_pmc_traffic profile)."""
+    import finenvs_amd
+
+    name, N, A, W = CONFIGS[args.config]
+    prices, day_id, _ = make_series(A)
+    obs_bytes = N * W * 5 * A * (4 if args.obs_f32 else 8)
+    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw=args.redraw, seed=1234,
+                                    obs_buffers=2 if 2 * obs_bytes < 200e9 else 1,
+                                    obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
+    env.reset()
+    for i in range(16):
+        env.step(actions[i % 8])
+    torch.cuda.synchronize()
 
 
 class Dist:
@@ -389,13 +452,29 @@ def main():
     ap.add_argument("--redraw", default="device", choices=["device", "torch"])
     ap.add_argument("--obs-f32", action="store_true", help="f32 observations (NOT the reference dtype; extra mode)")
     ap.add_argument("--graph", action="store_true", help="replay the 8-action ring as one hipGraph per 8 steps")
+    ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes")
+    ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
+    if args.pmc_child:
+        pmc_child(args)
+        return
 
     D = Dist(args)
     head = run_workload(args.config, args, D, args.steps, args.warmup, args.repeats,
                         with_cpu=(not args.no_cpu and D.world == 1))
     if "error" in head:
         sys.exit(f"bench.py: headline workload failed: {head['error']}")
+    def measure_traffic(res, config):
+        """roofline.traffic measured live (the workload's env is gone by now: the children have the card to themselves)."""
+        if D.world != 1 or args.no_pmc or args.graph or "error" in res:
+            return
+        t, src = live_pmc_traffic(config, args.obs_f32, args.redraw)
+        if t is not None:
+            res["roofline"]["traffic"], res["roofline"]["traffic_source"] = t, src
+        else:
+            res["roofline"]["traffic_source"] = f"{res['roofline']['traffic_source']} (live PMC pass unavailable: {src})"
+
+    measure_traffic(head, args.config)
     extras = []
     if not args.no_extra and not args.graph and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
         wanted = ([3, 4] if D.world == 1 else [5])
@@ -405,6 +484,7 @@ def main():
             k = min(args.steps, 20)
             try:
                 extras.append(run_workload(c, args, D, k, min(args.warmup, 5), 3, with_cpu=False))
+                measure_traffic(extras[-1], c)
             except Exception as exc:  # noqa: BLE001
                 extras.append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
                 break

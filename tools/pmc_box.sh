@@ -10,7 +10,7 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "TCC_HIT_sum TCC_MISS_sum TCC_EA0_WRREQ_sum TCC_EA0_RDREQ_sum" \
            "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
-  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 bench.py --config $CFG --steps 8 --warmup 4 --no-cpu --no-extra --repeats 2 > $OUT/b$i.json 2> $OUT/e$i.err || echo "pass $i failed"
+  rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 bench.py --config $CFG --steps 8 --warmup 4 --no-cpu --no-extra --no-pmc --repeats 2 > $OUT/b$i.json 2> $OUT/e$i.err || echo "pass $i failed"
 done
 python3 - <<PY
 import csv, glob, collections
