@@ -133,6 +133,9 @@ def pmc_traffic(config: int, f32: bool):
     return ent.get("bytes_per_launch"), f"profiles/hbm_traffic.json[{key}], run tag {ent.get('tag')} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
 
 
+_LIVE_PMC_BROKEN = []  # first failure of a live counter pass: later workloads fall back to the committed figures
+
+
 def live_pmc_traffic(config: int, f32: bool, redraw: str):
     """HBM traffic per launch MEASURED IN THIS RUN: two child processes of this very script (`--pmc-child`: the same
     workload, 16 launches) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, as
@@ -144,8 +147,11 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str):
     import subprocess
     import tempfile
 
+    if _LIVE_PMC_BROKEN:
+        return None, _LIVE_PMC_BROKEN[0]
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
+        _LIVE_PMC_BROKEN.append("rocprofv3 not found")
         return None, "rocprofv3 not found"
     out = tempfile.mkdtemp(prefix="fe_pmc_", dir="/tmp")
     vals = {}
@@ -156,9 +162,10 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str):
             if f32:
                 cmd.append("--obs-f32")
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=240)
+                               stderr=subprocess.DEVNULL, timeout=90)
             if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {kind} child exited with {r.returncode}"
+                _LIVE_PMC_BROKEN.append(f"rocprofv3 --pmc {kind} child exited with {r.returncode}")
+                return None, _LIVE_PMC_BROKEN[0]
             rows = []
             for f in glob.glob(os.path.join(out, kind, "*", "*_counter_collection.csv")):
                 for row in csv.DictReader(open(f)):
@@ -168,8 +175,9 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str):
                 return None, f"no {kind} rows for the step kernel"
             rows = rows[len(rows) // 4:]  # drop the warm-up launches
             vals[kind] = (sum(rows) / len(rows), len(rows))
-    except Exception as exc:  # noqa: BLE001
-        return None, f"{type(exc).__name__}: {exc}"
+    except Exception as exc:  # noqa: BLE001  (incl. the 90 s timeout: never try again in this run)
+        _LIVE_PMC_BROKEN.append(f"{type(exc).__name__}: {exc}")
+        return None, _LIVE_PMC_BROKEN[0]
     finally:
         shutil.rmtree(out, ignore_errors=True)
     traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
