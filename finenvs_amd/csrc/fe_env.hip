@@ -18,6 +18,16 @@
 // A workgroup (256 threads = 4 wavefronts of 64) owns a TILE of EB consecutive
 // envs; tiles are grid-strided.  The observation of a tile is one contiguous
 // region of HBM, so phase 2 is a flat, perfectly coalesced store stream.
+// Round-2 structure (measurements: DESIGN.md section 5, profiles/r02_microbench/):
+// workgroup barriers order LDS only (no store drain), observation stores are
+// write-through (sc1, single asset) or non-temporal (multi asset) so that state
+// and tables stay in L2, a single-asset tile is a whole number of workgroup
+// iterations with 4 (f64) / 6 (f32) workgroups per CU, and the first tile's table
+// loads are issued before its accounting.
+//
+// Also here: K-step fused rollouts with an in-kernel policy (linear window /
+// table form; two-layer MLP with the first layer on v_mfma_f32_32x32x2_f32),
+// init kernels (log-returns, day tables), the trajectory kernels, and the C ABI.
 //
 // Arithmetic contract: every (float)/(double) cast is a rounding point of the
 // reference's mixed f32/f64 tensor arithmetic; this file
