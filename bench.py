@@ -136,7 +136,7 @@ def pmc_traffic(config: int, f32: bool):
 _LIVE_PMC_BROKEN = []  # first failure of a live counter pass: later workloads fall back to the committed figures
 
 
-def live_pmc_traffic(config: int, f32: bool, redraw: str):
+def live_pmc_traffic(config: int, f32: bool, redraw: str, no_audition: bool = False):
     """HBM traffic per launch MEASURED IN THIS RUN: two child processes of this very script (`--pmc-child`: the same
     workload, 16 launches) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, as
     MI355X_MICROARCH.md's HBM section prescribes; both counters are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B
@@ -161,6 +161,8 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str):
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(config), "--redraw", redraw]
             if f32:
                 cmd.append("--obs-f32")
+            if no_audition:
+                cmd.append("--no-audition")
             r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL, timeout=90)
             if r.returncode != 0:
@@ -194,7 +196,7 @@ def pmc_child(args):
     prices, day_id, _ = make_series(A)
     obs_bytes = N * W * 5 * A * (4 if args.obs_f32 else 8)
     env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw=args.redraw, seed=1234,
-                                    obs_buffers=2 if 2 * obs_bytes < 200e9 else 1,
+                                    obs_buffers=2 if 2 * obs_bytes < 200e9 else 1, obs_audition=0 if args.no_audition else 5,
                                     obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
     g = torch.Generator(device="cuda:0").manual_seed(7)
     actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
@@ -280,6 +282,9 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         env = finenvs_amd.TimeSeriesEnv(
             prices=prices, day_id=day_id, num_intervals=W, num_envs=n_per_gpu * world, rank=rank, world_size=world,
             device_id=D.local_rank, redraw=args.redraw, seed=1234, obs_buffers=obs_buffers,
+            # ring mode's placement audition (a product feature of the ring): up to 5 more candidate
+            # buffers than the ring needs are tried at construction and the fastest kept (none fit at config 4)
+            obs_audition=0 if args.no_audition else 5,
             obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
         N = env.num_envs
         g = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -409,6 +414,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         "ms_per_step": block / steps * 1e3,
         "steps": steps, "warmup": warmup,
         "envs_per_gpu": N, "num_assets": A, "window": W, "obs_buffers": obs_buffers,
+        "obs_ring_audition": getattr(env, "obs_audition", None),
         "launch": env.launch_info(),
         "launch_mode": "hipGraph x8 steps" if args.graph else "eager, one launch per step",
         "repeats": {name_: {"blocks": len(v), "ms_per_step_median": statistics.median(v) / steps * 1e3,
@@ -460,6 +466,7 @@ def main():
     ap.add_argument("--redraw", default="device", choices=["device", "torch"])
     ap.add_argument("--obs-f32", action="store_true", help="f32 observations (NOT the reference dtype; extra mode)")
     ap.add_argument("--graph", action="store_true", help="replay the 8-action ring as one hipGraph per 8 steps")
+    ap.add_argument("--no-audition", action="store_true", help="take the observation ring as allocated (no placement audition)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -476,7 +483,7 @@ def main():
         """roofline.traffic measured live (the workload's env is gone by now: the children have the card to themselves)."""
         if D.world != 1 or args.no_pmc or args.graph or "error" in res:
             return
-        t, src = live_pmc_traffic(config, args.obs_f32, args.redraw)
+        t, src = live_pmc_traffic(config, args.obs_f32, args.redraw, args.no_audition)
         if t is not None:
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = t, src
         else:
@@ -513,7 +520,8 @@ def main():
             "data": "synthetic",
             "config": {"workload": head["workload"], "envs_per_gpu": head["envs_per_gpu"],
                        "num_assets": head["num_assets"], "window": head["window"],
-                       "obs_buffers": head["obs_buffers"], "eval_redraw": args.redraw,
+                       "obs_buffers": head["obs_buffers"], "obs_ring_audition": head["obs_ring_audition"],
+                       "eval_redraw": args.redraw,
                        "launch_mode": head["launch_mode"], "launch": head["launch"],
                        "timed_region": "median of R blocks of exactly `steps` steps, each between (barrier + synchronize) fences, max over ranks per block"},
             "repeats": head["repeats"],

@@ -13,7 +13,8 @@ current stream.  There is no CPU path.
 Keyword-only extensions: ``num_envs`` (env n -> day n mod D), ``num_assets`` /
 ``prices`` / ``day_id`` (tensor input, multi-asset "sleeve" contract of
 DESIGN.md), ``tables`` (ready-made (D,L,4A) price/log-return tables),
-``obs_dtype``, ``obs_buffers``, ``redraw``, ``seed``, ``env_indices``, ``rank`` /
+``obs_dtype``, ``obs_buffers`` (opt-in ring of env-owned observation buffers), ``obs_audition`` (ring mode:
+extra candidate buffers to try at construction, the fastest stay), ``redraw``, ``seed``, ``env_indices``, ``rank`` /
 ``world_size`` (contiguous env shards, one process per GPU).
 """
 from __future__ import annotations
@@ -63,6 +64,7 @@ class TimeSeriesEnv:
         tables=None,
         obs_dtype: torch.dtype = torch.float64,
         obs_buffers: int = 0,
+        obs_audition: int = 0,
         redraw: str = "torch",
         seed: int = 0,
         env_indices=None,
@@ -104,6 +106,8 @@ class TimeSeriesEnv:
             self._build_tables(from_files, prices, day_id, tables, num_assets)
             self.set_spaces()
             self.set_environment_params(num_envs, env_indices, obs_buffers)
+            if obs_audition > 0 and self.obs_buffers > 0:
+                self._audition_ring(int(obs_audition))
 
     # ------------------------------------------------------------------ init path
     def _stream(self) -> int:
@@ -261,6 +265,46 @@ class TimeSeriesEnv:
         self._obs_next = 0
         self._step_fn = self._lib.fe_env_step
         self._handle_v = handle.value
+
+    def _audition_ring(self, extra: int) -> None:
+        """Ring mode only.  HBM write bandwidth on MI355X depends on where a buffer lies (the same store kernel runs
+        5.7 ... 6.5 TB/s on different 20 GB allocations, reproducibly per buffer; tools/placement.hip, DESIGN.md
+        section 4), and the step kernel is bound by exactly that.  So: allocate up to ``extra`` more candidate
+        buffers than the ring needs (as far as free memory allows), time the observation render into each, keep
+        the fastest ``obs_buffers`` and give the rest back.  Values are unaffected; ``self.obs_audition`` records
+        what was measured."""
+        N, W, A = self.num_envs, self.num_intervals, self.num_assets
+        nbytes = N * W * 5 * A * (4 if self.obs_dtype == torch.float32 else 8)
+        free, _ = torch.cuda.mem_get_info(self._dev)
+        extra = int(max(0, min(extra, (free - (8 << 30)) // max(nbytes, 1))))
+        cands = list(self._obs_ring)
+        try:
+            for _ in range(extra):
+                cands.append(torch.empty((N, W, 5 * A), dtype=self.obs_dtype, device=self._dev))
+        except RuntimeError:  # out of memory: audition what we have
+            pass
+        if len(cands) <= self.obs_buffers:
+            self.obs_audition = {"candidates": len(cands), "us": [], "kept": list(range(len(cands)))}
+            return
+        st = self._stream()
+        times = []
+        for buf in cands:
+            best = float("inf")
+            for rep in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                _lib.check(self._lib.fe_env_reset_obs(self._handle, buf.data_ptr(), st))
+                e1.record()
+                e1.synchronize()
+                if rep:  # the first launch warms the tables
+                    best = min(best, e0.elapsed_time(e1) * 1e3)
+            times.append(best)
+        order = sorted(range(len(cands)), key=lambda i: times[i])
+        kept = sorted(order[: self.obs_buffers])
+        self._obs_ring = [cands[i] for i in kept]
+        self.obs_audition = {"candidates": len(cands), "us": [round(t, 2) for t in times], "kept": kept}
+        del cands
+        torch.cuda.empty_cache()
 
     def print(self) -> None:
         """Attribute dump, the reference's BaseObject.print (finenvs/base_object.py:7-9); device tensors

@@ -193,3 +193,24 @@ def test_fe_env_create_computes_the_log_return_table_when_passed_null(fe, fo):
         assert_bits(t2n(rew), r_r, f"step {t} rewards")
         assert_bits(t2n(done), d_r, f"step {t} dones")
     assert lib.fe_env_destroy(h) == 0
+
+
+def test_ring_audition_changes_placement_only(fe, fo):
+    """obs_audition (ring mode): extra candidate buffers are tried at construction and the fastest kept.  The ring
+    keeps its size, the record says what was measured, and every value equals the oracle / an un-auditioned env."""
+    P, LR = _tables(fo, 6, 2, 40, 8)
+    N, A, W = 700, 2, 8
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_buffers=2, obs_audition=4)
+    rec = env.obs_audition
+    assert len(env._obs_ring) == 2 and rec["candidates"] == 6 and len(rec["us"]) == 6 and len(rec["kept"]) == 2
+    assert all(t > 0 for t in rec["us"]) and rec["kept"] == sorted(rec["kept"])
+    ref = fo.OracleEnv(P, LR, W, num_envs=N, evaluate=True)
+    assert_bits(t2n(env.reset()), ref.reset(), "reset obs")
+    g = torch.Generator().manual_seed(3)
+    for t in range(50):
+        a = (torch.rand((N, A), generator=g) * 2 - 1).float()
+        o, r, d, _ = env.step(a.to(env.device))
+        o2, r2, d2, _ = ref.step(a.numpy())
+        assert_bits(t2n(o), o2, f"step {t} obs"); assert_bits(t2n(r), r2, f"step {t} rewards"); assert_bits(t2n(d), d2, f"step {t} dones")
+    plain = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_audition=4)  # fresh-tensor mode: ignored
+    assert not hasattr(plain, "obs_audition") and plain._obs_ring == []
