@@ -1440,15 +1440,16 @@ __device__ __forceinline__ void mlp_policy_block(const Params &p, const MlpArgs 
             acc[t][rr] = fmaf(pos32, s_wpos[h], s_b1[h]);
         }
     const float *wrow = s_w1t + (size_t)col * KP + 4 * half;
+    // rows past the window re-read its last row: their W1t entries are zero padding, so they contribute exactly
+    // fmaf(0, x, acc) -- and an unconditional load keeps the chunk loop free of branches (with a branch around
+    // the load the compiler waited vmcnt(0) at the top of every chunk, i.e. for the prefetch it had just issued)
     auto load_x = [&](int g) {
         const int row = 2 * g + half;
-        float4 x = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (row < W) x = *reinterpret_cast<const float4 *>(xsrc + (int64_t)row * rstride);
-        return x;
+        return *reinterpret_cast<const float4 *>(xsrc + (int64_t)(row < W ? row : W - 1) * rstride);
     };
     // First layer.  B operands (window rows, from L2) are fetched one chunk of CH row groups ahead -- a
     // chunk is CH * NT * 4 MFMAs of 64 cycles, several L2 round trips --; the chunk body has no control
-    // flow (rows past W read as zero, W1t is zero-padded to whole chunks), so the compiler is free to
+    // flow (rows past W re-read the last row, W1t is zero-padded to whole chunks), so the compiler is free to
     // hoist the LDS fragment reads over the MFMAs.
     constexpr int CH = kMlpChunk;
     const int nchunks = (ngroups + CH - 1) / CH;

@@ -525,7 +525,7 @@ void fo_policy_table_actions(const double *table, double wsum, double bias, cons
  * states.float() to their networks, PPO_agent.py:101; layer shape of multilayer_perceptron.py:17-25):
  *   pre[h]  = fmaf chain, start fmaf((float)pos, wpos[h], b1[h]), then the 4W log-return features in the order
  *             g = 0.. (two window rows per group, groups padded to a multiple of four), c = 0..3, row 2g before
- *             row 2g+1  (rows past W contribute fmaf(0, 0, acc)) -- the k order of the v_mfma_f32_32x32x2_f32
+ *             row 2g+1  (rows past W contribute fmaf(0, last row, acc)) -- the k order of the v_mfma_f32_32x32x2_f32
  *             chain of the HIP kernel;
  *   action  = clamp(b2 + (P0 + P1), -1, 1), P_half = fmaf chain over the hidden units
  *             32t + (r&3) + 8(r>>2) + 4*half, t and r ascending, of w2[h] * act(pre[h]).
@@ -552,7 +552,8 @@ void fo_policy_mlp(const double *obs, const float *w1t, const float *wpos, const
                     for (int c = 0; c < 4; ++c)
                         for (int half = 0; half < 2; ++half) {
                             const int row = 2 * g + half;
-                            const float x = row < W ? (float)o[(size_t)row * 5 * A + c] : 0.0f;
+                            const int rc = row < W ? row : W - 1;  /* padding rows: weight 0 times the last row */
+                            const float x = (float)o[(size_t)rc * 5 * A + c];
                             const float w = row < W ? w1t[(size_t)h * K4 + 4 * row + c] : 0.0f;
                             acc = fmaf(w, x, acc);
                         }
