@@ -119,3 +119,26 @@ def test_synthetic_generator_spec():
     assert np.all(p[:, 1] >= np.maximum(p[:, 0], p[:, 3]) - 1e-4) and np.all(p[:, 2] <= np.minimum(p[:, 0], p[:, 3]) + 1e-4)
     assert abs(p[0, 0] - 100) < 1 and abs(p[0, 4] - 110) < 1
     assert np.array_equal(np.round(p, 4), p)
+
+
+def test_bench_helpers_and_cli_parse_without_a_gpu():
+    """bench.py is what the driver runs unattended: its byte formulas, the repeat heuristic and the argument parser
+    must at least import and behave on the CPU (SURVEY 8d figures)."""
+    import importlib.util
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    # SURVEY 8(d): B = 72*W*A + 84*A + 36; the HBM part drops the 32*W*A window re-read
+    assert bench.survey_bytes(64, 1) == 4728 and bench.survey_bytes(64, 30) == 140796 and bench.survey_bytes(128, 30) == 279036
+    assert bench.hbm_bytes(64, 1, 8) == 2680 == bench.survey_bytes(64, 1) - 32 * 64
+    assert bench.hbm_bytes(128, 30, 8) == 156156 and bench.hbm_bytes(64, 1, 4) == 1400
+    assert bench.auto_repeats(7, 20, 3e-5) == 7 and 5 <= bench.auto_repeats(0, 20, 3.4e-5) <= 40
+    assert bench.auto_repeats(0, 20, 25e-3) == 5 and bench.auto_repeats(0, 20, 1e-6) == 40
+    assert set(bench.CONFIGS) == {1, 2, 3, 4, 5} and bench.CONFIGS[2][1:] == (65536, 1, 64)
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
