@@ -61,7 +61,7 @@ constexpr int kBlock = 256;
 //     the tables then stay L2-resident, which shortens the kernel's start-up chain (index load -> bar gather ->
 //     accounting -> first store): measured at 64k envs (tools/ab_step.py, interleaved in one process, three
 //     boxes) 34.8 -> 31.1, 34.5 -> 32.0, 34.8 -> 33.6 us per step; nt gains about 1 % less, sc0|sc1 the same.
-//   * multi-asset envs: nt.  Measured at 1M envs x 30 assets (round 1, tools/store_policy_box.sh): FETCH_SIZE
+//   * multi-asset envs: nt.  Measured at 1M envs x 30 assets (round 1, profiles/r01_microbench/store_policy.txt): FETCH_SIZE
 //     6.9 GiB -> 0.4 GiB per launch and 26.4 -> 25.0 ms; sc1 gives the same fetch reduction but 25.6 ms.
 // -1 = plain everywhere; -3 = the round-1 choice (plain for single-asset, nt for multi-asset); >= 0 = that aux
 // everywhere (experiment builds).
@@ -1818,7 +1818,7 @@ static int configure_launch(fe_env *env) {
     int64_t resident = (int64_t)env->cus * per_cu;
     if (resident > 8) resident -= resident % 8;  // keeps tile % 8 (the XCD label) constant per workgroup
     // Tile = EB consecutive envs.  Aim for ~8/3 tiles per resident workgroup: measured on
-    // MI355X (tools/sweep_tiles.py, 64k envs) a few short tiles per workgroup beat one long
+    // MI355X (round 1, profiles/r01_microbench/sweep_c2.txt, 64k envs) a few short tiles per workgroup beat one long
     // tile (workgroups drift apart, so phase 1 of one hides under phase 2 of its CU-mates).
     int64_t EB = (3 * cfg.N + 4 * resident) / (8 * resident);
     if (EB < 1) EB = 1;
