@@ -214,3 +214,22 @@ def test_ring_audition_changes_placement_only(fe, fo):
         assert_bits(t2n(o), o2, f"step {t} obs"); assert_bits(t2n(r), r2, f"step {t} rewards"); assert_bits(t2n(d), d2, f"step {t} dones")
     plain = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_audition=4)  # fresh-tensor mode: ignored
     assert not hasattr(plain, "obs_audition") and plain._obs_ring == []
+
+
+def test_single_asset_launch_geometry_rule(fe, fo):
+    """A single-asset tile is a whole number of phase-2 workgroup iterations (512 f64 / 1024 f32 tuples) and the grid is
+    capped at 4 (f64) / 6 (f32) workgroups per CU -- DESIGN.md section 5; set_launch overrides and restores it."""
+    from finenvs_amd.data import synthetic
+
+    prices, day_id, _ = synthetic.synthetic_series(8, 1, 200, 3)
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for W, dt, unit, per_cu in ((64, torch.float64, 8, 4), (64, torch.float32, 16, 6), (32, torch.float64, 16, 4), (100, torch.float64, 128, 4)):
+        env = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=65536, redraw="device", obs_dtype=dt)
+        info = env.launch_info()
+        assert info["tile_envs"] % unit == 0, (W, dt, info)
+        assert info["grid"] <= cus * per_cu and info["grid"] % 8 == 0, (W, dt, info)
+        over = env.set_launch(16, 512)
+        assert over["tile_envs"] == 16 and over["grid"] == 512
+        assert env.set_launch() == info  # 0 = automatic again
+    small = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=64, num_envs=100, redraw="device")
+    assert small.launch_info()["grid"] == (100 + small.launch_info()["tile_envs"] - 1) // small.launch_info()["tile_envs"]
