@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfinenvs_amd.so")
 
-FE_ABI_VERSION = 2
+FE_ABI_VERSION = 3
 FE_MAX_ASSETS = 256
 
 
@@ -49,6 +49,8 @@ SIGNATURES = {
     "fe_policy_table": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "fe_env_rollout_table": (C.c_int, [_vp, _vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_env_rollout_mlp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fe_env_rollout_lstm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fe_lstm_activations": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "fe_env_set_day": (C.c_int, [_vp, _i64, _i64, _vp]),
     "fe_env_launch_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "fe_env_destroy": (C.c_int, [_vp]),

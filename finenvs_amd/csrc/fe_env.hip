@@ -1574,6 +1574,274 @@ __global__ __launch_bounds__(kBlock, 2) void fe_rollout_mlp_kernel(const Params 
     }
 }
 
+// ---- f2, LSTM head: the actor of the reference's own time-series scripts, on the matrix cores ----
+// finenvs/agents/networks/lstm.py:28-57 -- nn.LSTM(5, H, batch_first) from a zero state over the W rows of the
+// observation, Linear(H, 1) on the last hidden state, Tanh (continuous_actor.py:104-126) -- evaluated on
+// states.float() per (env, asset) pair; examples/time_series/PPO_LSTM_testing_SPY.py:43-52 is the loop this fuses.
+// Per time step the gates are a (4H) x (H + 8) x (pairs) contraction, G^T = [Whh | Wx] . [h_{t-1} ; x_t]^T:
+//   * gate rows on the M side of v_mfma_f32_32x32x2_f32, 32 (env, asset) pairs on the N side; the rows are packed by
+//     the host so that an accumulator lane holds all four gates of four hidden units of ITS pair (row
+//     R = 32 mt + 8 b + 4 half + gate <-> unit 8 mt + 4 half + b): the cell update is in-lane, c_t never leaves
+//     the registers, and h_t goes to LDS as one 16-byte store per lane -- already in the [pair][unit] layout the next
+//     step's B operand reads with one ds_read_b128 per four MFMAs;
+//   * the recurrent weights stay in REGISTERS for the whole launch: Whh for H = 128 is 256 KiB, more than the LDS,
+//     but split over the 8 wavefronts of a 512-thread workgroup it is 128 VGPRs per lane (2 wavefronts per SIMD,
+//     256 VGPRs each); every wavefront owns MPW row tiles and runs all the workgroup's 32-pair column tiles;
+//   * the input part (K = 8: four log-returns | position, 1 for the bias, 0, 0) is four more MFMAs per tile;
+//   * the f32 MFMA is an fmaf chain in k order, and sigmoid / tanh are built from rintf, fmaf, ldexpf and IEEE
+//     division only (lstm_exp_nonpos), so the test-side CPU restatement (fo_policy_lstm) reproduces every
+//     action BIT FOR BIT; against torch's own nn.LSTM the actions agree to ~1e-7.
+// One barrier per time step (h double-buffered in LDS); the last hidden state is reduced by the pair's accounting lane.
+constexpr int kLstmBlock = 512;
+
+struct LstmArgs {
+    const float *lr32;  // (D, L, 4A) f32 copy of the log-return table
+    const float *whh;   // (4H, H) f32, packed row order
+    const float *wx;    // (4H, 8) f32, packed row order: w_ih[0..3], w_ih[4], b_ih + b_hh, 0, 0
+    const float *wout;  // (H)
+    float bout;
+    int32_t H, out_act, K;  // out_act: 0 tanh (the reference's actor), 1 clamp to [-1, 1]
+    int64_t *obs_src;
+    double *obs_pos;
+    float *actions_out;
+    double *rew_out;
+    int32_t *done_out;
+};
+
+template <int NT> struct LstmGeom {
+    static constexpr int H = 32 * NT;
+    static constexpr int MT = H / 8;                        // 32-row gate tiles
+    static constexpr int MPW = MT >= 8 ? MT / 8 : 1;        // row tiles per wavefront
+    static constexpr int NSPLIT = MT >= 8 ? 1 : 8 / MT;     // wavefronts sharing a row tile split the column tiles
+    static constexpr int SP = NT == 4 ? 64 : 128;           // (env, asset) pairs per workgroup tile
+    static constexpr int MAXNT = SP / 32 / NSPLIT;          // column tiles per wavefront
+    static constexpr int HP = H + 4;                        // LDS row length of h: 16 bytes against bank conflicts
+};
+
+__host__ __device__ inline size_t lstm_lds_bytes(int EB, int A, int H, int SP) {
+    size_t S = (size_t)EB * A;
+    size_t b = (size_t)EB * 8 + S * 8 + S * 8 + S * 4 + S * 4 + (size_t)EB * 4;  // TileLds
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)EB * 8;  // redrawn day per env
+    b = (b + 15) & ~(size_t)15;
+    b += 2 * (size_t)SP * (H + 4) * 4;  // h, double-buffered
+    b += (size_t)H * 4;                 // wout
+    return (b + 15) & ~(size_t)15;
+}
+
+// exp(y) for y <= 0 from exactly-rounded operations only (Cephes expf's reduction and polynomial): the same
+// sequence on the CPU (fo_exp_nonpos in the tests' restatement) gives the same bits
+__device__ __forceinline__ float lstm_exp_nonpos(float y) {
+    if (!(y == y)) return y;
+    y = y < -80.0f ? -80.0f : y;
+    const float n = rintf(y * 1.44269504f);
+    float r = fmaf(n, -0.693359375f, y);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float q = 1.9875691500e-4f;
+    q = fmaf(q, r, 1.3981999507e-3f);
+    q = fmaf(q, r, 8.3334519073e-3f);
+    q = fmaf(q, r, 4.1665795894e-2f);
+    q = fmaf(q, r, 1.6666665459e-1f);
+    q = fmaf(q, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    q = fmaf(q, r2, r);
+    q = q + 1.0f;
+    return ldexpf(q, (int)n);
+}
+
+__device__ __forceinline__ float lstm_sigmoid(float x) {
+    const float e = lstm_exp_nonpos(-fabsf(x));
+    const float d = 1.0f + e;
+    return x >= 0.0f ? 1.0f / d : e / d;
+}
+
+__device__ __forceinline__ float lstm_tanh(float x) {
+    const float e = lstm_exp_nonpos(-2.0f * fabsf(x));
+    const float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+__global__ __launch_bounds__(kBlock) void fe_lstm_activations_kernel(const float *x, float *sig, float *tnh, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        sig[i] = lstm_sigmoid(x[i]);
+        tnh[i] = lstm_tanh(x[i]);
+    }
+}
+
+template <bool SINGLE, int NT>
+__global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_kernel(const Params p, const LstmArgs r) {
+    using G = LstmGeom<NT>;
+    constexpr int H = G::H, HP = G::HP, MPW = G::MPW, NSPLIT = G::NSPLIT, MAXNT = G::MAXNT, NG = H / 8;
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const int S = EB * A;
+    const int W = p.W;
+    const TileLds l = carve_lds(smem, EB, S);
+    size_t off = (size_t)EB * 8 + (size_t)S * 8 + (size_t)S * 8 + (size_t)S * 4 + (size_t)S * 4 + (size_t)EB * 4;
+    off = (off + 7) & ~(size_t)7;
+    int64_t *l_idx = reinterpret_cast<int64_t *>(smem + off);
+    off = (off + (size_t)EB * 8 + 15) & ~(size_t)15;
+    float *s_h = reinterpret_cast<float *>(smem + off);  // [2][SP][HP]
+    float *s_wout = s_h + 2 * (size_t)G::SP * HP;
+    const int tid = threadIdx.x;
+    const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
+    const int a = SINGLE ? 0 : tid - e * A;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t NA = p.N * A;
+    const int64_t rstride = 4 * (int64_t)A;
+    const int mt0 = NSPLIT == 1 ? wave * MPW : wave % G::MT;  // first gate-row tile of this wavefront
+    const int nsub = NSPLIT == 1 ? 0 : wave / G::MT;          // its share of the column tiles
+
+    // this wavefront's slice of the weights: A fragments, lane (row = lane & 31, k half = lane >> 5)
+    float4 whh[MPW][NG], wx[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const size_t R = (size_t)32 * (mt0 + i) + col;
+        wx[i] = *reinterpret_cast<const float4 *>(r.wx + R * 8 + 4 * half);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) whh[i][g] = *reinterpret_cast<const float4 *>(r.whh + R * H + 8 * g + 4 * half);
+    }
+    for (int i = tid; i < H; i += kLstmBlock) s_wout[i] = r.wout[i];
+
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        const bool active = e < ebt;
+        const int64_t n = n0 + e;
+        const int64_t sl = n * A + a;
+        SleeveReg st;
+        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
+        st.obs_row = 0; st.obs_pos = 0.0;
+        if (active) {
+            st.idx = p.env_idx[n];
+            st.spot = p.spot0[n];
+            st.cash = p.cash[sl];
+            st.lng = p.lng[sl];
+            st.sht = p.sht[sl];
+            st.margin = p.margin[sl];
+            if (a == 0) l.src[e] = r.obs_src[n];
+            l.pos[e * A + a] = r.obs_pos[sl];
+        }
+        __syncthreads();  // also covers s_wout on the first tile
+        const int pairs = ebt * A;
+        const int ntiles = (pairs + 31) / 32;
+        for (int k = 0; k < r.K; ++k) {
+            // ---- policy: W recurrent steps, every wavefront its gate rows for all of its column tiles ----
+            const float *xsrc[MAXNT];
+            float4 xh[MAXNT], xc[MAXNT];
+            float cst[MPW][MAXNT][4];
+#pragma unroll
+            for (int j = 0; j < MAXNT; ++j) {
+                const int q = (nsub + j * NSPLIT) * 32 + col;
+                const int qc = q < pairs ? q : pairs - 1;
+                const int ee = SINGLE ? qc : (int)fdiv((uint32_t)qc, p.div_A);
+                const int aa = SINGLE ? 0 : qc - ee * A;
+                xsrc[j] = r.lr32 + l.src[ee] + 4 * aa;
+                xh[j] = make_float4((float)l.pos[qc], 1.0f, 0.0f, 0.0f);
+                xc[j] = half == 0 ? *reinterpret_cast<const float4 *>(xsrc[j]) : xh[j];
+#pragma unroll
+                for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) cst[i][j][b] = 0.0f;
+            }
+            for (int t = 0; t < W; ++t) {
+                const float *hprev = s_h + (size_t)((t + 1) & 1) * G::SP * HP;
+                float *hnext = s_h + (size_t)(t & 1) * G::SP * HP;
+                float4 xn[MAXNT];
+                const int tn = t + 1 < W ? t + 1 : t;  // the next step's rows, one step ahead of their use
+#pragma unroll
+                for (int j = 0; j < MAXNT; ++j)
+                    xn[j] = half == 0 ? *reinterpret_cast<const float4 *>(xsrc[j] + (int64_t)tn * rstride) : xh[j];
+#pragma unroll
+                for (int j = 0; j < MAXNT; ++j) {
+                    const int nt = nsub + j * NSPLIT;
+                    if (nt < ntiles) {
+                        f32x16 acc[MPW];
+#pragma unroll
+                        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                            for (int rr = 0; rr < 16; ++rr) acc[i][rr] = 0.0f;
+                        const float xs[4] = {xc[j].x, xc[j].y, xc[j].z, xc[j].w};
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int i = 0; i < MPW; ++i) {
+                                const float ws = m == 0 ? wx[i].x : (m == 1 ? wx[i].y : (m == 2 ? wx[i].z : wx[i].w));
+                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs[m], acc[i], 0, 0, 0);
+                            }
+                        if (t > 0) {
+                            const float *hrow = hprev + (size_t)(32 * nt + col) * HP + 4 * half;
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                const float4 hb = *reinterpret_cast<const float4 *>(hrow + 8 * g);
+                                const float hs[4] = {hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+                                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                    for (int i = 0; i < MPW; ++i) {
+                                        const float4 wv = whh[i][g];
+                                        const float ws = m == 0 ? wv.x : (m == 1 ? wv.y : (m == 2 ? wv.z : wv.w));
+                                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, hs[m], acc[i], 0, 0, 0);
+                                    }
+                            }
+                        }
+                        // cell update, in-lane: acc[i][4b + gate] belongs to unit 8 (mt0 + i) + 4 half + b
+#pragma unroll
+                        for (int i = 0; i < MPW; ++i) {
+                            float hv[4];
+#pragma unroll
+                            for (int b = 0; b < 4; ++b) {
+                                const float ig = lstm_sigmoid(acc[i][4 * b + 0]);
+                                const float fg = lstm_sigmoid(acc[i][4 * b + 1]);
+                                const float gg = lstm_tanh(acc[i][4 * b + 2]);
+                                const float og = lstm_sigmoid(acc[i][4 * b + 3]);
+                                const float t1 = fg * cst[i][j][b];
+                                const float t2 = ig * gg;
+                                const float cn = t1 + t2;
+                                cst[i][j][b] = cn;
+                                hv[b] = og * lstm_tanh(cn);
+                            }
+                            *reinterpret_cast<float4 *>(hnext + (size_t)(32 * nt + col) * HP + 8 * (mt0 + i) + 4 * half) =
+                                make_float4(hv[0], hv[1], hv[2], hv[3]);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MAXNT; ++j) xc[j] = xn[j];
+                lds_barrier();  // h_t is complete
+            }
+            // ---- output layer: the pair's accounting lane reduces its last hidden state ----
+            float act = 0.0f;
+            if (active) {
+                const float *hl = s_h + (size_t)((W - 1) & 1) * G::SP * HP + (size_t)(e * A + a) * HP;
+                float o = r.bout;
+#pragma unroll 8
+                for (int u = 0; u < H; ++u) o = fmaf(s_wout[u], hl[u], o);
+                act = r.out_act == 0 ? lstm_tanh(o) : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o));
+                if (r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
+            }
+            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
+                                 r.done_out + (int64_t)k * p.N);
+            lds_barrier();  // the new observation's descriptors are complete; everyone is done with h_W
+        }
+        if (active) {  // state and descriptors go back to HBM once per launch
+            p.cash[sl] = st.cash;
+            p.lng[sl] = st.lng;
+            p.sht[sl] = st.sht;
+            p.margin[sl] = st.margin;
+            r.obs_pos[sl] = l.pos[e * A + a];
+            if (a == 0) {
+                p.env_idx[n] = st.idx;
+                p.spot0[n] = st.spot;
+                r.obs_src[n] = l.src[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // descriptors of the current state's observation (reset() semantics), one lane per sleeve
 template <bool SINGLE>
 __global__ __launch_bounds__(kBlock) void fe_describe_kernel(const Params p, int64_t *obs_src, double *obs_pos) {
@@ -2211,6 +2479,61 @@ int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, c
     void *args[] = {&p, &r};
     he = hipLaunchKernel(kern, dim3((unsigned)grid), dim3(block), args, lds, (hipStream_t)stream);
     if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_mlp launch");
+    return FE_OK;
+}
+
+int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout,
+                        float bout, int32_t H, int32_t out_activation, int32_t K, int64_t *obs_src, double *obs_pos,
+                        float *actions_out, double *rewards_out, int32_t *dones_out, void *stream) {
+    if (!env || !logret_f32 || !whh || !wx || !wout || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: bad argument");
+    if (H != 32 && H != 64 && H != 128) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: H must be 32, 64 or 128 (got %d)", (int)H);
+    if (out_activation < 0 || out_activation > 1) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: out_activation must be 0 (tanh) or 1 (clamp)");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_lstm: state not bound");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    Params p = env->p;
+    LstmArgs r;
+    r.lr32 = logret_f32; r.whh = whh; r.wx = wx; r.wout = wout; r.bout = bout; r.H = H; r.out_act = out_activation; r.K = K;
+    r.obs_src = obs_src; r.obs_pos = obs_pos; r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
+    // SP (env, asset) pairs per workgroup: 2 (H = 128) or 4 column tiles of 32; an env's sleeves stay together
+    const int SP = H == 128 ? LstmGeom<4>::SP : LstmGeom<2>::SP;
+    if (p.A > SP)
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: %d assets per env exceed the %d pairs of a workgroup tile (H = %d)", (int)p.A, SP, (int)H);
+    int64_t eb = SP / p.A;
+    if (env->rollout_tile_override > 0 && env->rollout_tile_override < eb) eb = env->rollout_tile_override;
+    p.EB = (int)eb;
+    p.num_tiles = (p.N + eb - 1) / eb;
+    const size_t lds = lstm_lds_bytes(p.EB, p.A, H, SP);
+    const bool single = p.A == 1;
+#define FE_LSTM(NT) (single ? (const void *)fe_rollout_lstm_kernel<true, NT> : (const void *)fe_rollout_lstm_kernel<false, NT>)
+    const void *kern = H == 32 ? FE_LSTM(1) : (H == 64 ? FE_LSTM(2) : FE_LSTM(4));
+#undef FE_LSTM
+    hipError_t he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm: hipFuncSetAttribute");
+    int per_cu = 0;
+    he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kLstmBlock, lds);
+    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm: hipOccupancyMaxActiveBlocksPerMultiprocessor");
+    if (per_cu < 1) per_cu = 1;
+    const int64_t resident = (int64_t)env->cus * per_cu;  // the weights sit in registers: one pass of resident workgroups
+    const int64_t grid = p.num_tiles < resident ? p.num_tiles : resident;
+    void *args[] = {&p, &r};
+    he = hipLaunchKernel(kern, dim3((unsigned)grid), dim3(kLstmBlock), args, lds, (hipStream_t)stream);
+    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm launch");
+    return FE_OK;
+}
+
+int fe_lstm_activations(const float *x, float *sigmoid_out, float *tanh_out, int64_t n, void *stream) {
+    if (!x || !sigmoid_out || !tanh_out || n < 0) return fail(FE_ERR_ARG, "fe_lstm_activations: bad argument");
+    if (n == 0) return FE_OK;
+    DeviceGuard guard(device_of(x));
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    hipError_t he;
+    int64_t grid = (n + kBlock - 1) / kBlock;
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(fe_lstm_activations_kernel, dim3((unsigned)grid), dim3(kBlock), 0, (hipStream_t)stream, x, sigmoid_out, tanh_out, n);
+    he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_lstm_activations launch");
     return FE_OK;
 }
 

@@ -261,3 +261,104 @@ class FusedMLPRollout(_FusedEvaluation):
         _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
                                                obs.data_ptr(), self.env._stream()))
         return obs
+
+
+def lstm_row_order(H: int) -> torch.Tensor:
+    """Row of ``weight_hh_l0`` / ``weight_ih_l0`` (torch order: gate * H + unit, gates i, f, g, o) that packed row
+    R = 32*mt + 8*b + 4*half + gate holds: the hidden unit of R is 8*mt + 4*half + b, so that one accumulator lane of
+    the kernel's 32 x 32 MFMA tile carries all four gates of four units (include/finenvs_amd.h, fe_env_rollout_lstm)."""
+    R = torch.arange(4 * H)
+    mt, rho = R // 32, R % 32
+    gate, half, b = rho % 4, (rho % 8) // 4, rho // 8
+    return gate * H + 8 * mt + 4 * half + b
+
+
+class FusedLSTMRollout(_FusedEvaluation):
+    """K env steps per launch with the LSTM actor of the reference's time-series scripts evaluated in the kernel
+    (C ABI ``fe_env_rollout_lstm``):
+
+        actions = tanh(Linear(H, 1)(LSTM(5, H)(states.float())[:, -1, :]))         per (env, asset) pair
+
+    i.e. ``LSTMNetwork((5, H, 1), sequence_length=W, output_activation=nn.Tanh)`` of
+    finenvs/agents/networks/lstm.py:28-57 / finenvs/agents/PPO/continuous_actor.py:104-126 -- the network
+    examples/time_series/PPO_LSTM_testing_SPY.py:43-52 steps the evaluate-mode env with; ``evaluate_returns()`` is
+    that loop.  The gate contractions run on the MFMA units in f32, observations are never written to HBM.
+    Parameters are ``nn.LSTM``'s ``weight_ih_l0 (4H, 5)``, ``weight_hh_l0 (4H, H)``, ``bias_ih_l0``, ``bias_hh_l0``
+    and the output layer's ``weight (1, H)`` / ``bias``; ``H`` in {32, 64, 128}."""
+
+    OUTPUT_ACTIVATIONS = {"tanh": 0, "clamp": 1}
+
+    def __init__(self, env, weight_ih: torch.Tensor, weight_hh: torch.Tensor, bias_ih: torch.Tensor, bias_hh: torch.Tensor,
+                 weight_out: torch.Tensor, bias_out: float = 0.0, output_activation: str = "tanh"):
+        if weight_hh.dim() != 2 or weight_hh.shape[0] != 4 * weight_hh.shape[1]:
+            raise ValueError("weight_hh must be (4H, H)")
+        H = int(weight_hh.shape[1])
+        if H not in (32, 64, 128):
+            raise ValueError("H must be 32, 64 or 128")
+        if tuple(weight_ih.shape) != (4 * H, 5):
+            raise ValueError(f"weight_ih must be ({4 * H}, 5): the four log-returns and the position feature")
+        if output_activation not in self.OUTPUT_ACTIVATIONS:
+            raise ValueError(f"output_activation must be one of {sorted(self.OUTPUT_ACTIVATIONS)}")
+        if env.redraw != "device" and not env.evaluate:
+            raise ValueError('the fused rollout needs redraw="device" (or evaluate mode): no host in the loop')
+        self.env, self.H, self.out_act = env, H, self.OUTPUT_ACTIVATIONS[output_activation]
+        dev = env._dev
+        self.obs_src = torch.empty((env.num_envs,), dtype=torch.int64, device=dev)
+        self.obs_pos = torch.empty((env.num_envs, env.num_assets), dtype=torch.float64, device=dev)
+        self._lr32 = getattr(env, "_log_return_f32", None)
+        if self._lr32 is None:
+            self._lr32 = env.log_return_environments.float().contiguous()
+        self.set_weights(weight_ih, weight_hh, bias_ih, bias_hh, weight_out, bias_out)
+        self.sync_from_env()
+
+    @classmethod
+    def from_modules(cls, env, lstm: "torch.nn.LSTM", linear: "torch.nn.Linear", output_activation: str = "tanh"):
+        """From the two modules of the reference's LSTMNetwork (``.lstm`` and ``.last_layer[0]``)."""
+        if lstm.num_layers != 1 or lstm.bidirectional or lstm.input_size != 5 or linear.out_features != 1:
+            raise ValueError("expected nn.LSTM(5, H, num_layers=1) and nn.Linear(H, 1)")
+        return cls(env, lstm.weight_ih_l0, lstm.weight_hh_l0, lstm.bias_ih_l0, lstm.bias_hh_l0, linear.weight,
+                   float(linear.bias.detach()), output_activation)
+
+    def set_weights(self, weight_ih, weight_hh, bias_ih, bias_hh, weight_out, bias_out: float) -> None:
+        H, dev = self.H, self.env._dev
+        f32 = dict(dtype=torch.float32, device="cpu")
+        order = lstm_row_order(H)
+        w_ih, w_hh = weight_ih.detach().to(**f32), weight_hh.detach().to(**f32)
+        bias = bias_ih.detach().to(**f32).reshape(4 * H) + bias_hh.detach().to(**f32).reshape(4 * H)  # one f32 add
+        wx = torch.zeros((4 * H, 8), dtype=torch.float32)
+        wx[:, :5] = w_ih[order]
+        wx[:, 5] = bias[order]
+        self.whh = w_hh[order].contiguous().to(dev)
+        self.wx = wx.to(dev)
+        self.wout = weight_out.detach().to(dtype=torch.float32, device=dev).reshape(H).contiguous()
+        self.bout = float(bias_out)
+
+    def sync_from_env(self) -> None:
+        from . import _lib
+
+        _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                                                 self.env._stream()))
+
+    def run(self, num_steps: int, record_actions: bool = True):
+        """Returns (actions (K, N, A) f32 or None, rewards (K, N) f64, dones (K, N) int32)."""
+        from . import _lib
+
+        env, K = self.env, int(num_steps)
+        N, A = env.num_envs, env.num_assets
+        actions = torch.empty((K, N, A), dtype=torch.float32, device=env._dev) if record_actions else None
+        rewards = torch.empty((K, N), dtype=torch.float64, device=env._dev)
+        dones = torch.empty((K, N), dtype=torch.int32, device=env._dev)
+        _lib.check(env._lib.fe_env_rollout_lstm(
+            env._handle, self._lr32.data_ptr(), self.whh.data_ptr(), self.wx.data_ptr(), self.wout.data_ptr(), self.bout,
+            self.H, self.out_act, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+            actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
+        return actions, rewards, dones
+
+    def observation(self) -> torch.Tensor:
+        """The (N, W, 5A) observation the next policy evaluation will see."""
+        from . import _lib
+
+        obs = self.env._next_obs()
+        _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                                               obs.data_ptr(), self.env._stream()))
+        return obs

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FE_ABI_VERSION 2
+#define FE_ABI_VERSION 3
 #define FE_MAX_ASSETS 256
 
 #define FE_OK 0
@@ -194,6 +194,28 @@ int fe_env_rollout_table(fe_env *env, const double *table, const double *wsum, d
 int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, const float *wpos, const float *b1,
                        const float *w2, float b2, int32_t H, int32_t activation, int32_t K, int64_t *obs_src,
                        double *obs_pos, float *actions_out, double *rewards_out, int32_t *dones_out, void *stream);
+
+/*
+ * The same loop with the LSTM actor the reference's own time-series scripts use
+ * (finenvs/agents/networks/lstm.py:28-57: nn.LSTM(5, H, batch_first) from a zero state over the W rows of the
+ * observation, Linear(H, 1) on the last hidden state; Tanh output, finenvs/agents/PPO/continuous_actor.py:104-126;
+ * fed states.float(), examples/time_series/PPO_LSTM_testing_SPY.py:43-52), applied per (env, asset) pair.
+ * The gate contraction (4H) x (H + 8) x pairs of every time step runs on the matrix cores (v_mfma_f32_32x32x2_f32),
+ * the recurrent weights live in registers, c_t in registers, h_t in LDS.  Summation order and the exact-operation
+ * sigmoid / tanh are part of the contract and restated by oracle/fe_oracle.c:fo_policy_lstm (bit-reproducible):
+ *   whh (4H, H) f32: weight_hh_l0 with its rows PACKED: row 32*mt + 8*b + 4*half + gate = gate (0 i, 1 f, 2 g, 3 o)
+ *   of hidden unit 8*mt + 4*half + b;  wx (4H, 8) f32, same row order: weight_ih_l0[row][0..4], bias_ih + bias_hh,
+ *   0, 0;  wout (H), bout: the output layer;  H in {32, 64, 128};  out_activation 0 = tanh, 1 = clamp to [-1, 1].
+ * A (assets per env) must not exceed the pairs of a workgroup tile (64 for H = 128, else 128): FE_ERR_ARG.
+ * Other arguments, loop semantics and side effects as fe_env_rollout_linear.
+ */
+int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout,
+                        float bout, int32_t H, int32_t out_activation, int32_t K, int64_t *obs_src, double *obs_pos,
+                        float *actions_out, double *rewards_out, int32_t *dones_out, void *stream);
+
+/* Diagnostics: the sigmoid and tanh fe_env_rollout_lstm applies to nn.LSTM's gates (finenvs/agents/networks/lstm.py:28-34)
+ * and to the actor's output (continuous_actor.py:112), elementwise on n device floats: pins them against the oracle. */
+int fe_lstm_activations(const float *x, float *sigmoid_out, float *tanh_out, int64_t n, void *stream);
 
 /* env_indices[env] = day (the host half of TSE:510-513 when redraw_mode == 0). */
 int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream);

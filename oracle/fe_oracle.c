@@ -573,3 +573,105 @@ void fo_policy_mlp(const double *obs, const float *w1t, const float *wpos, const
         }
     free(pre);
 }
+
+/* ---- LSTM head of the fused rollout (finenvs_amd fe_env_rollout_lstm) ----
+ * The actor the reference's own time-series scripts use: finenvs/agents/networks/lstm.py:28-57 (nn.LSTM(5, H),
+ * batch_first, zero initial state, then Linear(H, 1) on the LAST hidden state) with the Tanh output activation of
+ * finenvs/agents/PPO/continuous_actor.py:104-126, applied to states.float()
+ * (examples/time_series/PPO_LSTM_testing_SPY.py:46) per (env, asset) pair.  This is the order-exact CPU form of the
+ * contract fe_env_rollout_lstm documents:
+ *   * gate rows are PACKED: row R = 32*mt + 8*b + 4*half + gate holds gate (0 i, 1 f, 2 g, 3 o; torch's order)
+ *     of hidden unit u = 8*mt + 4*half + b;  whh (4H, H) and wx (4H, 8) = [w_ih[.][0..3], w_ih[.][4], b_ih+b_hh, 0, 0]
+ *   * pre-activation of a row at time t: an fmaf chain from 0: for m = 0..3: wx[m]*x[m] then wx[4+m]*xh[m]
+ *     (x = the row's four log-returns as f32, xh = (position feature as f32, 1, 0, 0)); for t > 0 then, for
+ *     g = 0..H/8-1, m = 0..3: whh[8g+m]*h[8g+m] then whh[8g+4+m]*h[8g+4+m]
+ *   * sigmoid / tanh are the exact-operation forms below (rintf, fmaf, ldexpf, IEEE division only), so that the
+ *     device reproduces them bit for bit
+ *   * c = f*c + i*g (two products, one sum; c = i*g at t = 0), h = o*tanh(c)
+ *   * action = tanh(fmaf chain over u ascending of wout[u]*h_W[u] starting from bout)   (out_act 0), or that chain
+ *     clamped to [-1, 1] (out_act 1).
+ */
+static float fo_exp_nonpos(float y) { /* exp(y), y <= 0; Cephes expf's reduction and polynomial */
+    if (!(y == y)) return y;
+    y = y < -80.0f ? -80.0f : y;
+    const float n = rintf(y * 1.44269504f);
+    float r = fmaf(n, -0.693359375f, y);
+    r = fmaf(n, 2.12194440e-4f, r);
+    float p = 1.9875691500e-4f;
+    p = fmaf(p, r, 1.3981999507e-3f);
+    p = fmaf(p, r, 8.3334519073e-3f);
+    p = fmaf(p, r, 4.1665795894e-2f);
+    p = fmaf(p, r, 1.6666665459e-1f);
+    p = fmaf(p, r, 5.0000001201e-1f);
+    const float r2 = r * r;
+    p = fmaf(p, r2, r);
+    p = p + 1.0f;
+    return ldexpf(p, (int)n);
+}
+
+float fo_lstm_sigmoid(float x) {
+    const float e = fo_exp_nonpos(-fabsf(x));
+    const float d = 1.0f + e;
+    return x >= 0.0f ? 1.0f / d : e / d;
+}
+
+float fo_lstm_tanh(float x) {
+    const float e = fo_exp_nonpos(-2.0f * fabsf(x));
+    const float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+void fo_lstm_activations(const float *x, float *sig, float *tnh, int64_t n) {
+    for (int64_t i = 0; i < n; ++i) {
+        sig[i] = fo_lstm_sigmoid(x[i]);
+        tnh[i] = fo_lstm_tanh(x[i]);
+    }
+}
+
+void fo_policy_lstm(const double *obs, const float *whh, const float *wx, const float *wout, float bout, int32_t H,
+                    int32_t out_act, int64_t N, int32_t W, int32_t A, float *actions_out,
+                    float *h_out /* (N, A, H) or NULL */) {
+    float *h = (float *)calloc((size_t)H, sizeof(float)), *hn = (float *)calloc((size_t)H, sizeof(float));
+    float *c = (float *)calloc((size_t)H, sizeof(float));
+    for (int64_t n = 0; n < N; ++n)
+        for (int a = 0; a < A; ++a) {
+            const double *o = obs + (size_t)n * W * 5 * A + 5 * a;
+            for (int t = 0; t < W; ++t) {
+                const double *row = o + (size_t)t * 5 * A;
+                const float x[4] = {(float)row[0], (float)row[1], (float)row[2], (float)row[3]};
+                const float xh[4] = {(float)row[4], 1.0f, 0.0f, 0.0f};
+                for (int u = 0; u < H; ++u) {
+                    const int mt = u / 8, half = (u % 8) / 4, b = u % 4;
+                    float gate[4];
+                    for (int q = 0; q < 4; ++q) {
+                        const size_t R = (size_t)32 * mt + 8 * b + 4 * half + q;
+                        float acc = 0.0f;
+                        for (int m = 0; m < 4; ++m) {
+                            acc = fmaf(wx[R * 8 + m], x[m], acc);
+                            acc = fmaf(wx[R * 8 + 4 + m], xh[m], acc);
+                        }
+                        if (t > 0)
+                            for (int g = 0; g < H / 8; ++g)
+                                for (int m = 0; m < 4; ++m) {
+                                    acc = fmaf(whh[R * H + 8 * g + m], h[8 * g + m], acc);
+                                    acc = fmaf(whh[R * H + 8 * g + 4 + m], h[8 * g + 4 + m], acc);
+                                }
+                        gate[q] = acc;
+                    }
+                    const float ig = fo_lstm_sigmoid(gate[0]), fg = fo_lstm_sigmoid(gate[1]);
+                    const float gg = fo_lstm_tanh(gate[2]), og = fo_lstm_sigmoid(gate[3]);
+                    const float t1 = fg * (t > 0 ? c[u] : 0.0f), t2 = ig * gg;
+                    c[u] = t1 + t2;
+                    hn[u] = og * fo_lstm_tanh(c[u]);
+                }
+                float *sw = h; h = hn; hn = sw;
+            }
+            float acc = bout;
+            for (int u = 0; u < H; ++u) acc = fmaf(wout[u], h[u], acc);
+            if (h_out) memcpy(h_out + ((size_t)n * A + a) * H, h, sizeof(float) * (size_t)H);
+            if (out_act == 0) acc = fo_lstm_tanh(acc);
+            else acc = acc < -1.0f ? -1.0f : (acc > 1.0f ? 1.0f : acc);
+            actions_out[(size_t)n * A + a] = acc;
+        }
+    free(h); free(hn); free(c);
+}

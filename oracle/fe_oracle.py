@@ -177,6 +177,54 @@ def policy_mlp(obs: np.ndarray, w1t: np.ndarray, wpos: np.ndarray, b1: np.ndarra
     return (out, pre) if return_pre else out
 
 
+def lstm_row_order(H: int) -> np.ndarray:
+    """torch gate-row index (gate * H + unit) of every packed row R = 32*mt + 8*b + 4*half + gate, whose hidden
+    unit is 8*mt + 4*half + b (the order the kernel's accumulator registers hold the gates in)."""
+    R = np.arange(4 * H)
+    mt, rho = R // 32, R % 32
+    gate, half, b = rho % 4, (rho % 8) // 4, rho // 8
+    return gate * H + 8 * mt + 4 * half + b
+
+
+def lstm_pack(W_ih: np.ndarray, W_hh: np.ndarray, b_ih: np.ndarray, b_hh: np.ndarray):
+    """nn.LSTM(5, H) parameters (weight_ih_l0 (4H, 5), weight_hh_l0 (4H, H), bias_ih_l0, bias_hh_l0; gate order
+    i, f, g, o) -> (whh (4H, H), wx (4H, 8)) with rows in packed order and wx = [w_ih[0..3], w_ih[4], b_ih + b_hh
+    (one f32 add), 0, 0]."""
+    W_ih, W_hh = np.asarray(W_ih, dtype=np.float32), np.asarray(W_hh, dtype=np.float32)
+    H = W_hh.shape[1]
+    assert W_ih.shape == (4 * H, 5) and W_hh.shape == (4 * H, H)
+    order = lstm_row_order(H)
+    bias = (np.asarray(b_ih, dtype=np.float32) + np.asarray(b_hh, dtype=np.float32)).astype(np.float32)
+    wx = np.zeros((4 * H, 8), dtype=np.float32)
+    wx[:, :5] = W_ih[order]
+    wx[:, 5] = bias[order]
+    return np.ascontiguousarray(W_hh[order]), wx
+
+
+def policy_lstm(obs: np.ndarray, whh: np.ndarray, wx: np.ndarray, wout: np.ndarray, bout: float, out_act: int = 0,
+                return_h: bool = False):
+    """Actions (N, A) f32 of the in-kernel LSTM policy on a materialised observation (N, W, 5A)."""
+    obs = np.ascontiguousarray(obs, dtype=np.float64)
+    N, W, c5 = obs.shape
+    A = c5 // 5
+    whh, wx, wout = (np.ascontiguousarray(x, dtype=np.float32) for x in (whh, wx, wout))
+    H = whh.shape[1]
+    assert whh.shape == (4 * H, H) and wx.shape == (4 * H, 8) and wout.shape == (H,)
+    out = np.empty((N, A), dtype=np.float32)
+    h = np.empty((N, A, H), dtype=np.float32) if return_h else None
+    lib().fo_policy_lstm(_p(obs), _p(whh), _p(wx), _p(wout), C.c_float(bout), C.c_int32(H), C.c_int32(out_act),
+                         C.c_int64(N), C.c_int32(W), C.c_int32(A), _p(out), _p(h))
+    return (out, h) if return_h else out
+
+
+def lstm_activations(x: np.ndarray):
+    """(sigmoid, tanh) of the LSTM head's exact-operation activation forms, elementwise on f32."""
+    x = np.ascontiguousarray(x, dtype=np.float32)
+    sig, tnh = np.empty_like(x), np.empty_like(x)
+    lib().fo_lstm_activations(_p(x), _p(sig), _p(tnh), C.c_int64(x.size))
+    return sig, tnh
+
+
 def policy_table(LR: np.ndarray, weights: np.ndarray, W: int):
     """(table (D, L, A), wsum) of the table-form linear policy."""
     LR = np.ascontiguousarray(LR, dtype=np.float64)

@@ -332,6 +332,41 @@ def agent_stats_case():
     print("agent_stats.npz logs:", [(int(l[0]), int(l[3])) for l in logs])
 
 
+def lstm_actor_case():
+    """Runs the reference's own actor network of the time-series scripts -- ContinuousActorLSTM(shape=(5, H, 1),
+    sequence_length=W) (finenvs/agents/PPO/continuous_actor.py:104-126 over finenvs/agents/networks/lstm.py:7-57) --
+    on observations the reference env produced, exactly as examples/time_series/PPO_LSTM_testing_SPY.py:46 calls it
+    (``test_actor.forward(states.float())``), and records inputs, parameters and the actions it returned.  Pins the
+    LSTM head of the fused rollout (fo_policy_lstm / fe_env_rollout_lstm) at the tolerance stated in the tests."""
+    from finenvs.agents.PPO.continuous_actor import ContinuousActorLSTM
+
+    out = {}
+    for tag, H, W, steps in (("h128_w4", 128, 4, 12), ("h32_w8", 32, 8, 6)):
+        torch.manual_seed(4242 + H)
+        actor = ContinuousActorLSTM(shape=(5, H, 1), sequence_length=W)
+        with torch.no_grad():  # default init is tiny against log-returns of 1e-3: scale so that the gates move
+            actor.lstm.weight_ih_l0[:, :4].mul_(60.0 * np.sqrt(H))
+            actor.lstm.weight_ih_l0[:, 4].mul_(4.0)
+            actor.last_layer[0].weight.mul_(6.0)
+        env, _ = make_env("SYN_stress", W, starting_balance=800, evaluate=True)
+        states = env.reset()
+        obs, acts = [], []
+        for _ in range(steps):
+            actions = actor.forward(states.float()).detach()
+            obs.append(states.numpy().copy())
+            acts.append(actions.numpy().copy())
+            states, _, _, _ = env.step(actions)
+        sd = {k: v.detach().numpy().copy() for k, v in actor.state_dict().items()}
+        out.update({f"{tag}_obs": np.stack(obs), f"{tag}_actions": np.stack(acts), f"{tag}_H": np.int64(H),
+                    f"{tag}_W": np.int64(W), f"{tag}_weight_ih": sd["lstm.weight_ih_l0"],
+                    f"{tag}_weight_hh": sd["lstm.weight_hh_l0"], f"{tag}_bias_ih": sd["lstm.bias_ih_l0"],
+                    f"{tag}_bias_hh": sd["lstm.bias_hh_l0"], f"{tag}_weight_out": sd["last_layer.0.weight"],
+                    f"{tag}_bias_out": sd["last_layer.0.bias"]})
+        a = np.stack(acts)
+        print(f"lstm_actor {tag}: obs {np.stack(obs).shape} actions std {a.std():.3f} range [{a.min():.3f}, {a.max():.3f}]")
+    save_npz(os.path.join(GOLD, "lstm_actor.npz"), **out)
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     setup_reference()
@@ -516,6 +551,10 @@ def main():
     # ---------------- f4: the agents' return bookkeeping (PPO_agent.py:110-168) ----------------
     if wanted("agent_stats.npz"):
         agent_stats_case()
+
+    # ---------------- f2: the LSTM actor of the time-series scripts (lstm.py, continuous_actor.py) ----------------
+    if wanted("lstm_actor.npz"):
+        lstm_actor_case()
 
     # the reference tree must be untouched
     dirty = [p for p in glob.glob(os.path.join(REF, "finenvs", "data", "*", "*.json"))]

@@ -1,0 +1,215 @@
+"""GPU parity of the fused rollout's LSTM head (fe_env_rollout_lstm: the actor of the reference's own time-series
+scripts, gate contractions on the matrix cores, recurrent weights in registers).
+
+* the whole K-step rollout -- actions, rewards, dones, state -- equals the oracle's loop
+  ``actions = fo.policy_lstm(obs); obs, r, d = step(actions)`` BIT FOR BIT: the v_mfma_f32_32x32x2_f32 accumulation
+  is an fmaf chain whose order oracle/fe_oracle.c:fo_policy_lstm restates, and sigmoid / tanh are built from
+  exactly-rounded operations only (rintf, fmaf, ldexpf, IEEE division), the same sequence on both sides;
+* against torch's own ``nn.LSTM`` + ``nn.Linear`` + ``tanh`` in fp32 on the rendered observation (what
+  finenvs/agents/networks/lstm.py:49-57 computes): 1e-5 absolute -- a different summation order and libm's
+  exp/tanh; that is the tolerance north_star states for floating point.
+"""
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    import finenvs_amd
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return finenvs_amd
+
+
+@pytest.fixture(scope="module")
+def fo():
+    from oracle import fe_oracle
+
+    fe_oracle.build()
+    return fe_oracle
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def _tables(fo, num_days, A, bars, W, seed=1234, drop=0.0):
+    from finenvs_amd.data import synthetic
+
+    prices, day_id, _ = synthetic.synthetic_series(num_days, A, bars, seed, drop)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    return P, LR
+
+
+def _modules(H, seed, gain=6.0):
+    """nn.LSTM(5, H) + nn.Linear(H, 1) with torch's default init, the input weights scaled up so that log-returns of
+    ~1e-3..5e-2 move the gates and the actions spread over (-1, 1)."""
+    torch.manual_seed(seed)
+    lstm = torch.nn.LSTM(5, H, num_layers=1, batch_first=True)
+    lin = torch.nn.Linear(H, 1)
+    with torch.no_grad():
+        lstm.weight_ih_l0[:, :4].mul_(gain * np.sqrt(H))
+        lstm.weight_ih_l0[:, 4].mul_(4.0)
+        lin.weight.mul_(6.0)
+    return lstm, lin
+
+
+def _packed(fo, lstm, lin):
+    whh, wx = fo.lstm_pack(t2n(lstm.weight_ih_l0), t2n(lstm.weight_hh_l0), t2n(lstm.bias_ih_l0), t2n(lstm.bias_hh_l0))
+    return whh, wx, t2n(lin.weight).reshape(-1).copy(), float(lin.bias.detach())
+
+
+def _make(fe, fo, N, A, W, days, bars, drop, evaluate, seed):
+    P, LR = _tables(fo, days, A, bars, W, seed=seed, drop=drop)
+    D = P.shape[0]
+    idx = (np.arange(N) * 7 + 1) % D  # 7 is coprime to every day count used here: all days are in play
+    kw = dict(num_intervals=W, evaluate=evaluate, starting_balance=2000)
+    ref = fo.OracleEnv(P, LR, env_indices=idx, redraw_mode=1, seed=9, auto_emit=False, **kw)
+    ref.redraw_counter[0] = 1
+    env = fe.TimeSeriesEnv(tables=(P, LR), env_indices=idx, redraw="device", seed=9, **kw)
+    return ref, env
+
+
+def test_lstm_activations_equal_oracle_bit_for_bit(fe, fo):
+    """sigmoid / tanh of the LSTM head on 1.3 M inputs (dense sweep, normal draws, edge values): device == oracle
+    bit for bit, and both within 1e-7 of the f64 functions."""
+    from finenvs_amd import _lib
+
+    rng = np.random.default_rng(0)
+    x = np.concatenate([np.linspace(-100, 100, 1_000_001), rng.normal(0, 3, 300_000), rng.normal(0, 1e-3, 10_000),
+                        [0.0, -0.0, 1e-8, -1e-8, 1e-38, 88.0, -88.0, 1e30, -1e30, np.inf, -np.inf]]).astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    sig, tnh = torch.empty_like(xd), torch.empty_like(xd)
+    lib = _lib.load()
+    _lib.check(lib.fe_lstm_activations(xd.data_ptr(), sig.data_ptr(), tnh.data_ptr(), x.size, torch.cuda.current_stream().cuda_stream))
+    s_ref, t_ref = fo.lstm_activations(x)
+    assert_bits(t2n(sig), s_ref, "sigmoid")
+    assert_bits(t2n(tnh), t_ref, "tanh")
+    x64 = x.astype(np.float64)
+    with np.errstate(over="ignore"):
+        assert np.abs(s_ref - 1.0 / (1.0 + np.exp(-x64))).max() < 1e-7
+    assert np.abs(t_ref - np.tanh(x64)).max() < 1e-7
+
+
+@pytest.mark.parametrize("N,A,W,H,days,bars,drop,evaluate", [
+    (300, 1, 4, 32, 6, 40, 0.0, False),       # the reference scripts' window (num_intervals=4)
+    (500, 1, 4, 128, 5, 60, 0.05, False),     # PPOAgentLSTM's default hidden_dim = 128
+    (77, 3, 7, 64, 4, 40, 0.0, False),        # odd W, several sleeves
+    (21, 30, 4, 32, 5, 40, 0.1, True),        # DJIA-shaped sleeves, evaluate mode
+    (40, 30, 5, 128, 5, 40, 0.0, False),      # 30 sleeves, 2 envs per 64-pair tile
+    (131, 5, 1, 64, 6, 45, 0.1, False),       # W = 1: no recurrent step at all
+    (260, 1, 16, 32, 5, 50, 0.0, False),      # partial last tile (260 = 2 x 128 + 4)
+])
+def test_lstm_rollout_equals_oracle_loop_bit_for_bit(fe, fo, N, A, W, H, days, bars, drop, evaluate):
+    from finenvs_amd.rollout import FusedLSTMRollout
+
+    ref, env = _make(fe, fo, N, A, W, days, bars, drop, evaluate, seed=3 * N + W)
+    lstm, lin = _modules(H, seed=W + H)
+    whh, wx, wout, bout = _packed(fo, lstm, lin)
+    roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    assert_bits(t2n(roll.whh), whh, "packed Whh")
+    assert_bits(t2n(roll.wx), wx, "packed Wx")
+    obs = ref.reset().copy()
+    assert_bits(t2n(roll.observation()), obs, "initial obs")
+    K, reps = 5, 2 * (bars + 3) // 5 + 1
+    seen = set()
+    for rep in range(reps):
+        acts, rews, dones = roll.run(K)
+        for k in range(K):
+            a_ref = fo.policy_lstm(obs, whh, wx, wout, bout)
+            seen.update(np.unique(np.clip(np.rint(a_ref * 5.5), -5, 5)).tolist())
+            obs, r_ref, d_ref, _ = ref.step(a_ref)
+            obs = obs.copy()
+            what = f"replay {rep} step {k}"
+            assert_bits(t2n(acts[k]), a_ref, what + " actions")
+            assert_bits(t2n(rews[k]), r_ref, what + " rewards")
+            assert_bits(t2n(dones[k]), d_ref, what + " dones")
+        assert_bits(t2n(env.cash), ref.cash, f"replay {rep} cash")
+        assert_bits(t2n(env.margin), ref.margin, f"replay {rep} margin")
+        assert_bits(t2n(env.env_indices), ref.env_idx, f"replay {rep} env_idx")
+        assert_bits(t2n(env.env_spots[:, 0]), ref.spot0, f"replay {rep} spot0")
+        assert_bits(t2n(roll.observation()), obs, f"replay {rep} observation()")
+        if evaluate and int(ref.n_terminated[0]) == N:
+            env.reset_evaluation_metrics()
+            ref.terminated[:] = 0; ref.episode_returns[:] = 0; ref.n_terminated[0] = 0
+    assert len(seen) >= 4, f"the policy must actually trade in both directions (share changes seen: {sorted(seen)})"
+
+
+def test_lstm_head_against_torch_nn_lstm_fp32(fe, fo):
+    """tanh(Linear(LSTM(states.float())[:, -1, :])) with torch's own modules, per asset, on the rendered observation:
+    within 1e-5 absolute of the in-kernel head (measured ~1e-7); clamp output form as well."""
+    from finenvs_amd.rollout import FusedLSTMRollout
+
+    N, A, W, H = 500, 3, 4, 128
+    ref, env = _make(fe, fo, N, A, W, 5, 100, 0.0, False, seed=21)
+    lstm, lin = _modules(H, seed=0)
+    roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    worst = 0.0
+    for t in range(40):
+        obs = roll.observation().float().cpu()
+        with torch.no_grad():
+            want = torch.stack([torch.tanh(lin(lstm(obs[:, :, 5 * a:5 * a + 5])[0][:, -1, :])).squeeze(1) for a in range(A)], dim=1)
+        acts, _, _ = roll.run(1)
+        worst = max(worst, float((acts[0].cpu() - want).abs().max()))
+        torch.testing.assert_close(acts[0].cpu(), want, rtol=0, atol=1e-5)  # tolerance: 1e-5 absolute
+    assert float(want.abs().max()) > 0.05 and float(want.std()) > 0.01
+    print(f"worst |kernel - torch nn.LSTM| action difference {worst:.3g}")
+    clamp = FusedLSTMRollout.from_modules(env, lstm, lin, output_activation="clamp")
+    obs = clamp.observation().float().cpu()
+    with torch.no_grad():
+        want = torch.stack([lin(lstm(obs[:, :, 5 * a:5 * a + 5])[0][:, -1, :]).squeeze(1) for a in range(A)], dim=1).clamp(-1, 1)
+    acts, _, _ = clamp.run(1)
+    torch.testing.assert_close(acts[0].cpu(), want, rtol=0, atol=1e-5)
+
+
+def test_lstm_rollout_argument_errors(fe, fo):
+    from finenvs_amd._lib import FinEnvsNativeError
+    from finenvs_amd.rollout import FusedLSTMRollout
+
+    ref, env = _make(fe, fo, 10, 1, 4, 5, 40, 0.0, False, seed=1)
+    z = torch.zeros
+    with pytest.raises(ValueError):
+        FusedLSTMRollout(env, z((4 * 48, 5)), z((4 * 48, 48)), z(4 * 48), z(4 * 48), z(48))      # H not 32/64/128
+    with pytest.raises(ValueError):
+        FusedLSTMRollout(env, z((128, 4)), z((128, 32)), z(128), z(128), z(32))                  # wrong input size
+    with pytest.raises(ValueError):
+        FusedLSTMRollout(env, z((128, 5)), z((128, 32)), z(128), z(128), z(32), output_activation="relu")
+    with pytest.raises(ValueError):
+        FusedLSTMRollout.from_modules(env, torch.nn.LSTM(5, 32, num_layers=2), torch.nn.Linear(32, 1))
+    # more sleeves per env than a workgroup tile holds is refused, not mis-tiled
+    P, LR = _tables(fo, 3, 70, 30, 4)
+    wide = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=4, num_envs=4, redraw="device")
+    lstm, lin = _modules(128, seed=1)
+    roll = FusedLSTMRollout.from_modules(wide, lstm, lin)
+    with pytest.raises(FinEnvsNativeError, match="assets"):
+        roll.run(1)
+
+
+def test_lstm_evaluation_loop_returns_match_stepwise_oracle(fe, fo):
+    """FusedLSTMRollout.evaluate_returns = the reference's evaluation loop (PPO_LSTM_testing_SPY.py:43-52:
+    ``actions = test_actor.forward(states.float())`` until ``"returns" in info``), K steps per launch: the per-env
+    episode returns equal the oracle stepped one action at a time, bit for bit."""
+    from finenvs_amd.rollout import FusedLSTMRollout
+
+    N, A, W, H = 90, 1, 4, 64
+    ref, env = _make(fe, fo, N, A, W, 6, 40, 0.1, True, seed=5)
+    lstm, lin = _modules(H, seed=2)
+    whh, wx, wout, bout = _packed(fo, lstm, lin)
+    roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    got = t2n(roll.evaluate_returns(chunk=16))
+    ref.auto_emit = True
+    obs = ref.reset().copy()
+    want = None
+    for _ in range(2000):
+        obs, _, _, info = ref.step(fo.policy_lstm(obs, whh, wx, wout, bout))
+        obs = obs.copy()
+        if "returns" in info:
+            want = info["returns"]
+            break
+    assert want is not None
+    assert_bits(got, want, "episode returns")
