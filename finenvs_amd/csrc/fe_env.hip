@@ -1629,49 +1629,83 @@ __host__ __device__ inline size_t lstm_lds_bytes(int EB, int A, int H, int SP) {
     return (b + 15) & ~(size_t)15;
 }
 
-// exp(y) for y <= 0 from exactly-rounded operations only (Cephes expf's reduction and polynomial): the same
-// sequence on the CPU (fo_exp_nonpos in the tests' restatement) gives the same bits
-__device__ __forceinline__ float lstm_exp_nonpos(float y) {
-    if (!(y == y)) return y;
-    y = y < -80.0f ? -80.0f : y;
-    const float n = rintf(y * 1.44269504f);
-    float r = fmaf(n, -0.693359375f, y);
-    r = fmaf(n, 2.12194440e-4f, r);
-    float q = 1.9875691500e-4f;
-    q = fmaf(q, r, 1.3981999507e-3f);
-    q = fmaf(q, r, 8.3334519073e-3f);
-    q = fmaf(q, r, 4.1665795894e-2f);
-    q = fmaf(q, r, 1.6666665459e-1f);
-    q = fmaf(q, r, 5.0000001201e-1f);
-    const float r2 = r * r;
-    q = fmaf(q, r2, r);
-    q = q + 1.0f;
-    return ldexpf(q, (int)n);
+// ---- the LSTM head's sigmoid / tanh: exactly-rounded operations only, two activations per instruction ----
+//   e = exp(-s |x|) (s = 1 sigmoid, 2 tanh; argument clamped at -60), Cephes expf's reduction and polynomial;
+//   sigmoid = (x >= 0 ? 1 : e) / (1 + e),   tanh = copysign((1 - e) / (1 + e), x).
+// Every step is an IEEE-exact f32 operation (mul, fma, rint, ldexp, and a division), so the same sequence on the CPU
+// (fo_lstm_sigmoid / fo_lstm_tanh of the tests' restatement) gives the same bits.  The f32 MFMA shares the vector
+// ALUs with these (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so their instruction count is kernel time: the chains run on
+// pairs of activations with packed-f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), and the division
+// is the correctly-rounded rcp + fma sequence the compiler itself emits for `/`, minus its v_div_scale / v_div_fixup
+// range handling -- the denominator is in [1, 2] and the numerator in {0} U [2^-87, 1], where that handling is the
+// identity (this is why the argument clamp is -60: a smaller numerator would need the scaling).
+// NaN is not propagated (a NaN pre-activation acts like -60); the host refuses non-finite weights.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_splat(float v) { return (v2f){v, v}; }
+
+__device__ __forceinline__ v2f lstm_exp_nonpos2(v2f y0) {
+    v2f y = {fmaxf(y0.x, -60.0f), fmaxf(y0.y, -60.0f)};
+    v2f n = y * pk_splat(1.44269504f);
+    n = (v2f){rintf(n.x), rintf(n.y)};
+    v2f r = pk_fma(n, pk_splat(-0.693359375f), y);
+    r = pk_fma(n, pk_splat(2.12194440e-4f), r);
+    v2f q = pk_splat(1.9875691500e-4f);
+    q = pk_fma(q, r, pk_splat(1.3981999507e-3f));
+    q = pk_fma(q, r, pk_splat(8.3334519073e-3f));
+    q = pk_fma(q, r, pk_splat(4.1665795894e-2f));
+    q = pk_fma(q, r, pk_splat(1.6666665459e-1f));
+    q = pk_fma(q, r, pk_splat(5.0000001201e-1f));
+    const v2f r2 = r * r;
+    q = pk_fma(q, r2, r);
+    q = q + pk_splat(1.0f);
+    return (v2f){ldexpf(q.x, (int)n.x), ldexpf(q.y, (int)n.y)};
 }
 
-__device__ __forceinline__ float lstm_sigmoid(float x) {
-    const float e = lstm_exp_nonpos(-fabsf(x));
-    const float d = 1.0f + e;
-    return x >= 0.0f ? 1.0f / d : e / d;
+// num / den, correctly rounded, for den in [1, 2] and num in {0} U [2^-87, 1] (see above)
+__device__ __forceinline__ v2f lstm_div2(v2f num, v2f den) {
+    v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const v2f e0 = pk_fma(-den, r, pk_splat(1.0f));
+    r = pk_fma(e0, r, r);
+    v2f q = num * r;
+    v2f rem = pk_fma(-den, q, num);
+    q = pk_fma(rem, r, q);
+    rem = pk_fma(-den, q, num);
+    return pk_fma(rem, r, q);
 }
 
-__device__ __forceinline__ float lstm_tanh(float x) {
-    const float e = lstm_exp_nonpos(-2.0f * fabsf(x));
-    const float t = (1.0f - e) / (1.0f + e);
-    return copysignf(t, x);
+// two activations at once; T0 / T1: the element is a tanh (else a sigmoid)
+template <bool T0, bool T1>
+__device__ __forceinline__ v2f lstm_act2(v2f x) {
+    const v2f ax = {fabsf(x.x), fabsf(x.y)};
+    const v2f e = lstm_exp_nonpos2(ax * (v2f){T0 ? -2.0f : -1.0f, T1 ? -2.0f : -1.0f});
+    const v2f den = pk_splat(1.0f) + e;
+    v2f num;
+    num.x = T0 ? 1.0f - e.x : (x.x >= 0.0f ? 1.0f : e.x);
+    num.y = T1 ? 1.0f - e.y : (x.y >= 0.0f ? 1.0f : e.y);
+    v2f v = lstm_div2(num, den);
+    if (T0) v.x = copysignf(v.x, x.x);
+    if (T1) v.y = copysignf(v.y, x.y);
+    return v;
 }
+
+__device__ __forceinline__ float lstm_tanh(float x) { return lstm_act2<true, true>((v2f){x, x}).x; }
 
 __global__ __launch_bounds__(kBlock) void fe_lstm_activations_kernel(const float *x, float *sig, float *tnh, int64_t n) {
     for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
-        sig[i] = lstm_sigmoid(x[i]);
-        tnh[i] = lstm_tanh(x[i]);
+        const v2f v = lstm_act2<false, true>((v2f){x[i], x[i]});
+        sig[i] = v.x;
+        tnh[i] = v.y;
     }
 }
 
 template <bool SINGLE, int NT>
-__global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_kernel(const Params p, const LstmArgs r) {
+__global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm_kernel(const Params p, const LstmArgs r) {
     using G = LstmGeom<NT>;
     constexpr int H = G::H, HP = G::HP, MPW = G::MPW, NSPLIT = G::NSPLIT, MAXNT = G::MAXNT, NG = H / 8;
+    constexpr int JB = MPW == 1 ? 2 : 1;  // column tiles processed together
+    static_assert(MAXNT % JB == 0, "column tiles per wavefront must come in whole groups");
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
@@ -1754,58 +1788,75 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_kernel(const Pa
 #pragma unroll
                 for (int j = 0; j < MAXNT; ++j)
                     xn[j] = half == 0 ? *reinterpret_cast<const float4 *>(xsrc[j] + (int64_t)tn * rstride) : xh[j];
+                // JB column tiles at a time: with MPW row tiles that is MPW * JB >= 2 independent accumulator chains,
+                // so a dependent MFMA never waits for its predecessor's 16 passes
 #pragma unroll
-                for (int j = 0; j < MAXNT; ++j) {
-                    const int nt = nsub + j * NSPLIT;
-                    if (nt < ntiles) {
-                        f32x16 acc[MPW];
+                for (int j0 = 0; j0 < MAXNT; j0 += JB) {
+                    if (nsub + j0 * NSPLIT < ntiles) {  // (a trailing tile of the group past `pairs` computes on clamped rows)
+                        f32x16 acc[MPW][JB];
 #pragma unroll
                         for (int i = 0; i < MPW; ++i)
 #pragma unroll
-                            for (int rr = 0; rr < 16; ++rr) acc[i][rr] = 0.0f;
-                        const float xs[4] = {xc[j].x, xc[j].y, xc[j].z, xc[j].w};
+                            for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                                for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = 0.0f;
 #pragma unroll
                         for (int m = 0; m < 4; ++m)
 #pragma unroll
-                            for (int i = 0; i < MPW; ++i) {
-                                const float ws = m == 0 ? wx[i].x : (m == 1 ? wx[i].y : (m == 2 ? wx[i].z : wx[i].w));
-                                acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs[m], acc[i], 0, 0, 0);
-                            }
+                            for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                                for (int jj = 0; jj < JB; ++jj) {
+                                    const float4 xv = xc[j0 + jj];
+                                    const float xs = m == 0 ? xv.x : (m == 1 ? xv.y : (m == 2 ? xv.z : xv.w));
+                                    const float ws = m == 0 ? wx[i].x : (m == 1 ? wx[i].y : (m == 2 ? wx[i].z : wx[i].w));
+                                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, acc[i][jj], 0, 0, 0);
+                                }
                         if (t > 0) {
-                            const float *hrow = hprev + (size_t)(32 * nt + col) * HP + 4 * half;
 #pragma unroll
                             for (int g = 0; g < NG; ++g) {
-                                const float4 hb = *reinterpret_cast<const float4 *>(hrow + 8 * g);
-                                const float hs[4] = {hb.x, hb.y, hb.z, hb.w};
+                                float4 hb[JB];
+#pragma unroll
+                                for (int jj = 0; jj < JB; ++jj)
+                                    hb[jj] = *reinterpret_cast<const float4 *>(
+                                        hprev + (size_t)(32 * (nsub + (j0 + jj) * NSPLIT) + col) * HP + 4 * half + 8 * g);
 #pragma unroll
                                 for (int m = 0; m < 4; ++m)
 #pragma unroll
-                                    for (int i = 0; i < MPW; ++i) {
-                                        const float4 wv = whh[i][g];
-                                        const float ws = m == 0 ? wv.x : (m == 1 ? wv.y : (m == 2 ? wv.z : wv.w));
-                                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, hs[m], acc[i], 0, 0, 0);
-                                    }
+                                    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                                        for (int jj = 0; jj < JB; ++jj) {
+                                            const float4 wv = whh[i][g];
+                                            const float ws = m == 0 ? wv.x : (m == 1 ? wv.y : (m == 2 ? wv.z : wv.w));
+                                            const float hs = m == 0 ? hb[jj].x : (m == 1 ? hb[jj].y : (m == 2 ? hb[jj].z : hb[jj].w));
+                                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, hs, acc[i][jj], 0, 0, 0);
+                                        }
                             }
                         }
-                        // cell update, in-lane: acc[i][4b + gate] belongs to unit 8 (mt0 + i) + 4 half + b
+                        // cell update, in-lane: acc[i][jj][4b + gate] belongs to unit 8 (mt0 + i) + 4 half + b
 #pragma unroll
-                        for (int i = 0; i < MPW; ++i) {
-                            float hv[4];
+                        for (int i = 0; i < MPW; ++i)
 #pragma unroll
-                            for (int b = 0; b < 4; ++b) {
-                                const float ig = lstm_sigmoid(acc[i][4 * b + 0]);
-                                const float fg = lstm_sigmoid(acc[i][4 * b + 1]);
-                                const float gg = lstm_tanh(acc[i][4 * b + 2]);
-                                const float og = lstm_sigmoid(acc[i][4 * b + 3]);
-                                const float t1 = fg * cst[i][j][b];
-                                const float t2 = ig * gg;
-                                const float cn = t1 + t2;
-                                cst[i][j][b] = cn;
-                                hv[b] = og * lstm_tanh(cn);
+                            for (int jj = 0; jj < JB; ++jj) {
+                                const int j = j0 + jj;
+                                float hv[4], og[4];
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const v2f sif = lstm_act2<false, false>((v2f){acc[i][jj][4 * b + 0], acc[i][jj][4 * b + 1]});
+                                    const v2f tgo = lstm_act2<true, false>((v2f){acc[i][jj][4 * b + 2], acc[i][jj][4 * b + 3]});
+                                    const float t1 = sif.y * cst[i][j][b];
+                                    const float t2 = sif.x * tgo.x;
+                                    cst[i][j][b] = t1 + t2;
+                                    og[b] = tgo.y;
+                                }
+#pragma unroll
+                                for (int b = 0; b < 4; b += 2) {
+                                    const v2f tc = lstm_act2<true, true>((v2f){cst[i][j][b], cst[i][j][b + 1]});
+                                    hv[b] = og[b] * tc.x;
+                                    hv[b + 1] = og[b + 1] * tc.y;
+                                }
+                                *reinterpret_cast<float4 *>(hnext + (size_t)(32 * (nsub + j * NSPLIT) + col) * HP + 8 * (mt0 + i) + 4 * half) =
+                                    make_float4(hv[0], hv[1], hv[2], hv[3]);
                             }
-                            *reinterpret_cast<float4 *>(hnext + (size_t)(32 * nt + col) * HP + 8 * (mt0 + i) + 4 * half) =
-                                make_float4(hv[0], hv[1], hv[2], hv[3]);
-                        }
                     }
                 }
 #pragma unroll

@@ -324,6 +324,9 @@ class FusedLSTMRollout(_FusedEvaluation):
         f32 = dict(dtype=torch.float32, device="cpu")
         order = lstm_row_order(H)
         w_ih, w_hh = weight_ih.detach().to(**f32), weight_hh.detach().to(**f32)
+        for name, t in (("weight_ih", w_ih), ("weight_hh", w_hh), ("bias_ih", bias_ih), ("bias_hh", bias_hh), ("weight_out", weight_out)):
+            if not bool(torch.isfinite(t.detach()).all()):  # the kernel's activations do not propagate NaN
+                raise ValueError(f"{name} has non-finite entries")
         bias = bias_ih.detach().to(**f32).reshape(4 * H) + bias_hh.detach().to(**f32).reshape(4 * H)  # one f32 add
         wx = torch.zeros((4 * H, 8), dtype=torch.float32)
         wx[:, :5] = w_ih[order]

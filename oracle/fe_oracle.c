@@ -591,9 +591,9 @@ void fo_policy_mlp(const double *obs, const float *w1t, const float *wpos, const
  *   * action = tanh(fmaf chain over u ascending of wout[u]*h_W[u] starting from bout)   (out_act 0), or that chain
  *     clamped to [-1, 1] (out_act 1).
  */
-static float fo_exp_nonpos(float y) { /* exp(y), y <= 0; Cephes expf's reduction and polynomial */
-    if (!(y == y)) return y;
-    y = y < -80.0f ? -80.0f : y;
+static float fo_exp_nonpos(float y) { /* exp(y), y <= 0 (clamped at -60; a NaN acts like -60); Cephes expf's
+                                       * reduction and polynomial */
+    y = fmaxf(y, -60.0f);
     const float n = rintf(y * 1.44269504f);
     float r = fmaf(n, -0.693359375f, y);
     r = fmaf(n, 2.12194440e-4f, r);
