@@ -23,7 +23,8 @@ asynchronous trajectory all-gather (the headline `value`; one whole gather per t
 After the headline workload (BASELINE.json's "64k envs" configuration) the same process runs
 the larger BASELINE configs for a few steps each and reports them under "extra_configs" -- on
 one GPU configs 3 and 4 (the 1M-env north-star run), on N > 1 GPUs the per-GPU shard of
-config 5 (4M envs over 8 GPUs).  Prints ONE JSON line on rank 0.
+config 5 (4M envs over 8 GPUs); at N = 1 also three fused-rollout legs ("fused_rollouts": K steps per launch
+with an in-kernel linear / MLP / LSTM policy; never part of `value`).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -454,6 +455,64 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     return res
 
 
+def fused_rollout_legs(args):
+    """SURVEY 8f.2 legs, reported beside the headline (never part of `value`): K env steps per launch with the policy
+    evaluated in the kernel, at the headline's 65 536 envs x 1 asset.  The observation is never written to HBM, so these
+    are not HBM-roofline numbers: the MLP / LSTM legs report the f32 MFMA rate of their contractions instead."""
+    import finenvs_amd
+    from finenvs_amd.rollout import FusedLinearRollout, FusedLSTMRollout, FusedMLPRollout
+
+    _, N, A, _ = CONFIGS[2]
+    prices, day_id, _ = make_series(A)
+    g = torch.Generator().manual_seed(0)
+    legs = []
+    for form, W, K in (("linear_table", 64, 32), ("mlp_h64", 64, 32), ("lstm_h128", 4, 8)):
+        try:
+            env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw=args.redraw,
+                                            seed=1234, obs_buffers=1)
+            flop = 0.0
+            if form == "linear_table":
+                roll = FusedLinearRollout(env, torch.randn((W, 5), dtype=torch.float64, generator=g) * 2, 0.0, form="table")
+                policy = "clamp(<window, weights (W, 5)>), log-return part precomputed as an indicator table"
+            elif form == "mlp_h64":
+                H = 64
+                roll = FusedMLPRollout(env, torch.randn((5 * W, H), generator=g) * (8.0 / W ** 0.5), torch.randn(H, generator=g) * 0.3,
+                                       torch.randn(H, generator=g) / H ** 0.5, 0.0)
+                flop = 2.0 * N * A * (4 * W) * H
+                policy = "Linear(5W, 64) -> ELU -> Linear(64, 1), first layer on v_mfma_f32_32x32x2_f32"
+            else:
+                H = 128
+                torch.manual_seed(0)
+                lstm, lin = torch.nn.LSTM(5, H, batch_first=True), torch.nn.Linear(H, 1)
+                with torch.no_grad():
+                    lstm.weight_ih_l0[:, :4].mul_(6.0 * H ** 0.5)
+                roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+                flop = 2.0 * N * A * 4 * H * (8 * W + H * (W - 1))
+                policy = "the reference's actor: LSTM(5, 128) over the W rows -> Linear(128, 1) -> tanh, gates on v_mfma_f32_32x32x2_f32"
+            roll.run(K, record_actions=True)
+            times = []
+            for _ in range(3):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize()
+                e0.record()
+                roll.run(K, record_actions=True)
+                e1.record()
+                torch.cuda.synchronize()
+                times.append(e0.elapsed_time(e1) / K)
+            ms = statistics.median(times)
+            leg = {"form": form, "policy": policy, "envs": N, "num_assets": A, "window": W, "steps_per_launch": K,
+                   "us_per_step": round(ms * 1e3, 2), "value": round(N / ms * 1e3, 1), "unit": "env-steps/s"}
+            if flop:
+                leg["mfma_f32_tflops"] = round(flop / ms / 1e9, 1)
+                leg["mfma_f32_peak_tflops"] = 157.3
+            legs.append(leg)
+            del env, roll
+            torch.cuda.empty_cache()
+        except Exception as exc:  # noqa: BLE001
+            legs.append({"form": form, "error": f"{type(exc).__name__}: {exc}"})
+    return legs
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -504,6 +563,10 @@ def main():
                 extras.append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
                 break
 
+    fused = None
+    if D.world == 1 and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
+        fused = fused_rollout_legs(args)
+
     if D.rank == 0:
         out = {
             "metric": "env-steps/sec",
@@ -529,6 +592,7 @@ def main():
             "cpu_baseline": head.get("cpu_baseline"),
             "multi_gpu": head.get("multi_gpu"),
             "extra_configs": [{k: v for k, v in e.items() if k != "cpu_baseline"} for e in extras],
+            "fused_rollouts": fused,
         }
         print(json.dumps(out), flush=True)
     if D.dist is not None:
