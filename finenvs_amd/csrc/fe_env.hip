@@ -67,6 +67,9 @@ constexpr int kBlock = 256;
 // everywhere (experiment builds).
 // "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their
 // -D set here and are only ever loaded by explicit path
+#ifndef FE_NO_DESC   /* experiment builds only: compile the step kernel's descriptor outputs out (A/B of their cost) */
+#define FE_NO_DESC 0
+#endif
 #ifndef FE_BUILD_TAG
 #define FE_BUILD_TAG ""
 #endif
@@ -168,6 +171,8 @@ struct Params {
     void *obs;
     double *rew;
     int32_t *done;
+    int64_t *desc_src;   // optional (fe_env_step_described): descriptors of the observation this step returns
+    double *desc_pos;
     int64_t N, D, L;
     int64_t num_tiles;
     int64_t eval_env;
@@ -476,6 +481,12 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             const int64_t s0c = s0 + W <= L ? s0 : L - W;
             l.src[e] = (in.idx * L + s0c) * rs;
         }
+#if !FE_NO_DESC
+        if (p.desc_src) {  // the returned observation as descriptors, 8 + 8A bytes per env (a trajectory's `states`)
+            p.desc_pos[sl] = s.pos_obs;
+            if (a == 0) p.desc_src[n] = l.src[e];
+        }
+#endif
     }
     // ---------------- phase 1b: one lane per env ----------------
     bool any = sdone;
@@ -2104,12 +2115,14 @@ static const void *kernel_for(bool f32, int vec, bool single) {
 // modified by reset/step, so concurrent calls on different streams do not race on the host side.
 template <bool RESET_ONLY>
 static int launch_env(const fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
-                      hipStream_t st) {
+                      hipStream_t st, int64_t *desc_src = nullptr, double *desc_pos = nullptr) {
     Params p = env->p;
     p.actions = actions;
     p.obs = obs;
     p.rew = rewards;
     p.done = dones;
+    p.desc_src = desc_src;
+    p.desc_pos = desc_pos;
     void *args[] = {&p};
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
@@ -2366,6 +2379,14 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
     return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream);
 }
 
+int fe_env_step_described(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                          int64_t *obs_src_out, double *obs_pos_out, void *stream) {
+    if (!env || !actions || !obs || !rewards || !dones || !obs_src_out || !obs_pos_out)
+        return fail(FE_ERR_ARG, "fe_env_step_described: null argument");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step_described: state not bound");
+    return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream, obs_src_out, obs_pos_out);
+}
+
 int fe_env_describe(fe_env *env, int64_t *obs_src, double *obs_pos, void *stream) {
     if (!env || !obs_src || !obs_pos) return fail(FE_ERR_ARG, "fe_env_describe: null argument");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_describe: state not bound");
@@ -2383,13 +2404,21 @@ int fe_env_describe(fe_env *env, int64_t *obs_src, double *obs_pos, void *stream
 }
 
 int fe_env_render(fe_env *env, const int64_t *obs_src, const double *obs_pos, void *obs, void *stream) {
-    if (!env || !obs_src || !obs_pos || !obs) return fail(FE_ERR_ARG, "fe_env_render: null argument");
+    if (!env) return fail(FE_ERR_ARG, "fe_env_render: null argument");
+    return fe_env_render_n(env, obs_src, obs_pos, env->cfg.N, obs, stream);
+}
+
+int fe_env_render_n(fe_env *env, const int64_t *obs_src, const double *obs_pos, int64_t count, void *obs, void *stream) {
+    if (!env || !obs_src || !obs_pos || !obs || count < 0) return fail(FE_ERR_ARG, "fe_env_render_n: bad argument");
+    if (count == 0) return FE_OK;
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     Params p = env->p;
     p.obs = obs;
+    p.N = count;  // any number of descriptors, e.g. a minibatch drawn from a trajectory of them
+    p.num_tiles = (count + p.EB - 1) / p.EB;
     const bool f32 = env->cfg.obs_is_f32 != 0, single = p.A == 1;
-    dim3 g(env->grid), b(kBlock);
+    dim3 g((unsigned)(p.num_tiles < (int64_t)env->grid ? p.num_tiles : (int64_t)env->grid)), b(kBlock);
     hipStream_t st = (hipStream_t)stream;
     const size_t lds = env->lds;
 #define FE_RENDER(OT, VEC)                                                                                 \
@@ -2407,7 +2436,7 @@ int fe_env_render(fe_env *env, const int64_t *obs_src, const double *obs_pos, vo
     }
 #undef FE_RENDER
     hipError_t he = hipGetLastError();
-    if (he != hipSuccess) return hip_fail(he, "fe_env_render launch");
+    if (he != hipSuccess) return hip_fail(he, "fe_env_render_n launch");
     return FE_OK;
 }
 

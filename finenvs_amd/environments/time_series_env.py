@@ -364,13 +364,62 @@ class TimeSeriesEnv:
         """Render the observation of the current state (TSE:423-435; it resets nothing)."""
         obs = self._next_obs()
         _lib.check(self._lib.fe_env_reset_obs(self._handle, obs.data_ptr(), self._stream()))
+        self._last_descriptors, self._stepped = None, False  # the caller now looks at the current state again
         return obs
 
+    def last_observation_descriptors(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Descriptors of the observation most recently handed to the caller: what the last ``step`` recorded through
+        ``descriptors_out``, or -- after ``reset()`` / construction -- the current state's.  (After a done step the
+        returned observation is the terminal window, TSE:321, which the post-reset state no longer describes: a step
+        without ``descriptors_out`` leaves nothing to return here.)"""
+        if getattr(self, "_last_descriptors", None) is not None:
+            return self._last_descriptors
+        if getattr(self, "_stepped", False):
+            raise RuntimeError("the last step() was not given descriptors_out: its observation cannot be described "
+                               "after the fact (call reset() to look at the current state instead)")
+        return self.describe()
+
+    def describe(self, src_out: Optional[torch.Tensor] = None, pos_out: Optional[torch.Tensor] = None
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """The observation ``reset()`` would render now, as DESCRIPTORS: ``obs_src (N,) int64`` (window offset into
+        the log-return table) and ``obs_pos (N, A) float64`` (position feature) -- 8 + 8A bytes per env instead of
+        40WA.  ``render`` turns descriptors back into observations, on this or any other rank (the tables are
+        replicated).  A trajectory of descriptors (``TrajectoryBuffer(states=True)``) is the ``states`` field of the
+        reference's PPO buffer (finenvs/agents/PPO/buffer.py:33-56) without its bytes."""
+        N, A = self.num_envs, self.num_assets
+        src = src_out if src_out is not None else torch.empty((N,), dtype=torch.int64, device=self._dev)
+        pos = pos_out if pos_out is not None else torch.empty((N, A), dtype=torch.float64, device=self._dev)
+        for t, shape, dt in ((src, (N,), torch.int64), (pos, (N, A), torch.float64)):
+            if tuple(t.shape) != shape or t.dtype is not dt or not t.is_contiguous() or t.device != self._dev:
+                raise ValueError(f"descriptor outputs must be contiguous {shape} {dt} tensors on {self._dev}")
+        _lib.check(self._lib.fe_env_describe(self._handle, src.data_ptr(), pos.data_ptr(), self._stream()))
+        return src, pos
+
+    def render(self, obs_src: torch.Tensor, obs_pos: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Observations ``(B, W, 5A)`` (this env's ``obs_dtype``) of ANY B descriptors -- e.g. a minibatch drawn from
+        a trajectory of them (PPO_agent.py:175-188 indexes minibatches out of the stored states)."""
+        B, A = int(obs_src.numel()), self.num_assets
+        src = obs_src.reshape(B).to(device=self._dev, dtype=torch.int64).contiguous()
+        pos = obs_pos.reshape(B, A).to(device=self._dev, dtype=torch.float64).contiguous()
+        shape = (B, self.num_intervals, 5 * A)
+        if out is None:
+            out = torch.empty(shape, dtype=self.obs_dtype, device=self._dev)
+        elif tuple(out.shape) != shape or out.dtype is not self.obs_dtype or not out.is_contiguous() or out.device != self._dev:
+            raise ValueError(f"out must be a contiguous {shape} {self.obs_dtype} tensor on {self._dev}")
+        if B:  # (empty tensors have no storage to point at)
+            _lib.check(self._lib.fe_env_render_n(self._handle, src.data_ptr(), pos.data_ptr(), B, out.data_ptr(), self._stream()))
+        return out
+
     def step(self, actions: torch.Tensor, rewards_out: Optional[torch.Tensor] = None,
-             dones_out: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, dict]:
+             dones_out: Optional[torch.Tensor] = None,
+             descriptors_out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+             ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, dict]:
         """One fused launch of TSE:277-296.  Returns (obs (N,W,5A), rewards (N,) f64,
         dones (N,) int32, info).  ``rewards_out`` / ``dones_out`` let the kernel write straight into
-        caller-owned storage (e.g. a TrajectoryBuffer slot) instead of fresh tensors."""
+        caller-owned storage (e.g. a TrajectoryBuffer slot) instead of fresh tensors;
+        ``descriptors_out = (obs_src (N,) int64, obs_pos (N, A) float64)`` additionally receives the returned
+        observation as descriptors (``render`` turns them back into it): the ``next_states`` of the reference's loop
+        for a trajectory that keeps states without their bytes (``TrajectoryBuffer(states=True).state_slot()``)."""
         N, A = self.num_envs, self.num_assets
         if actions.dtype is not torch.float32:
             actions = actions.float()  # the reference's in-repo callers all pass f32 (SURVEY App. A iii)
@@ -391,8 +440,18 @@ class TimeSeriesEnv:
             dones = dones_out
             if dones.dtype is not torch.int32 or dones.numel() != N or not dones.is_contiguous() or dones.device != self._dev:
                 raise ValueError("dones_out must be a contiguous int32 tensor of num_envs elements on the env's device")
-        rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
-                           self._stream())
+        if descriptors_out is None:
+            rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
+                               self._stream())
+        else:
+            src, pos = descriptors_out
+            for t, count, dt in ((src, N, torch.int64), (pos, N * A, torch.float64)):
+                if t.dtype is not dt or t.numel() != count or not t.is_contiguous() or t.device != self._dev:
+                    raise ValueError("descriptors_out must be contiguous (int64 (N,), float64 (N, A)) tensors on the env's device")
+            rc = self._lib.fe_env_step_described(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
+                                                 dones.data_ptr(), src.data_ptr(), pos.data_ptr(), self._stream())
+        self._last_descriptors = descriptors_out  # None: the observation just returned was not recorded
+        self._stepped = True
         if rc != 0:
             _lib.check(rc)
         info: Dict = {}

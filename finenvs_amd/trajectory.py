@@ -12,6 +12,13 @@ exchange is ``all_gather`` of these compact fields -- actions (T, n, A) f32,
 rewards (T, n) f64, dones (T, n) i32 -- once per T-step chunk, as ONE collective
 over a single packed byte buffer (RCCL over xGMI when the process group is
 "nccl").  Observations are never gathered: they stay sharded with their learner.
+
+``states=True`` adds the reference buffer's ``states`` field (buffer.py:46, one (N, 1, W, 5) f64 ``torch.cat`` per
+step) as DESCRIPTORS: per env-step the window offset ``obs_src`` (i64) and the position features ``obs_pos`` (A f64)
+-- 8 + 8A bytes instead of 40WA (16 B against 2 560 B at W = 64; 248 B against 153 600 B for 30 assets at W = 128,
+where T steps of a million envs would not fit any memory).  ``states`` / ``minibatch_states`` render them through
+``env.render`` when the learner asks (PPO_agent.py:175-188), and because the tables are replicated the gathered
+descriptors of OTHER ranks render too: the all-gather then carries the complete PPO sample, states included.
 """
 from __future__ import annotations
 
@@ -26,7 +33,7 @@ _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 class TrajectoryBuffer:
     def __init__(self, num_steps: int, num_envs: int, num_assets: int = 1, device: str = "cuda:0",
-                 host_rehearsal: bool = False, capacity: Optional[int] = None):
+                 host_rehearsal: bool = False, capacity: Optional[int] = None, states: bool = False):
         """``capacity`` (>= num_envs, same on every rank) sizes the env axis of the buffers, so that ranks
         owning shards of different sizes (N not divisible by the world size) can still exchange chunks with
         one all-gather; ``join_shards`` drops the padding again."""
@@ -38,15 +45,31 @@ class TrajectoryBuffer:
         if self.device.type != "cuda" and not host_rehearsal:
             raise RuntimeError("TrajectoryBuffer lives in HBM; host tensors are accepted only with host_rehearsal=True, "
                                "which exists to rehearse the all-gather plumbing over gloo (no kernels run there)")
+        self.has_states = bool(states)
         T, N, A = self.T, self.C, self.A  # the env axis is laid out with `capacity` slots
-        # one allocation per chunk, three typed views: [rewards f64 | actions f32 | dones i32];
+        # one allocation per chunk, typed views, 8-byte fields first:
+        #   [rewards f64 | obs_pos f64, obs_src i64 (states=True) | actions f32 | dones i32];
         # two chunks so that a chunk can be in flight on the collective stream while the next fills
-        self._nbytes = T * N * 8 + T * N * A * 4 + T * N * 4
+        # state descriptors have T + 1 rows: row t is the observation the policy saw at step t, row T the one the
+        # last step returned (the `current_states` PPO_agent.py:171 bootstraps its values from)
+        fields = [("rewards", torch.float64, (), T)]
+        if self.has_states:
+            fields += [("obs_pos", torch.float64, (A,), T + 1), ("obs_src", torch.int64, (), T + 1)]
+        fields += [("actions", torch.float32, (A,), T), ("dones", torch.int32, (), T)]
+        self._layout, off = {}, 0
+        for name, dt, trail, rows in fields:
+            nb = rows * N * (A if trail else 1) * torch.empty((), dtype=dt).element_size()
+            self._layout[name] = (off, nb, dt, trail, rows)
+            off += nb
+        self._nbytes = off
         self._chunks = [torch.zeros((self._nbytes,), dtype=torch.uint8, device=self.device) for _ in range(2)]
         self._views = [self._typed(c) for c in self._chunks]
         # per-slot views, built once (tensor indexing costs microseconds of host time per call)
         n = self.N
         self._slots = [[(v[0][t, :n], v[1][t, :n], v[2][t, :n]) for t in range(T)] for v in self._views]
+        self._state_views = [self._typed_states(c) for c in self._chunks] if self.has_states else None
+        self._state_slots = ([[(v[0][t, :n], v[1][t, :n]) for t in range(T + 1)] for v in self._state_views]
+                             if self.has_states else None)
         self._pending = [None, None]   # outstanding collective per chunk
         self._gathered = [None, None]  # its output buffer
         self._cur = 0
@@ -54,18 +77,21 @@ class TrajectoryBuffer:
         self._native = self.device.type == "cuda"
         self._lib = _lib.load() if self._native else None
 
-    def _typed(self, packed: torch.Tensor, lead: Tuple[int, ...] = ()):
-        T, N, A = self.T, self.C, self.A
-        o1 = T * N * 8
-        o2 = o1 + T * N * A * 4
-        flat = packed.reshape(-1, self._nbytes) if lead else packed
+    def _field(self, packed: torch.Tensor, name: str, lead: Tuple[int, ...] = ()) -> torch.Tensor:
+        N = self.C
+        off, nb, dt, trail, rows = self._layout[name]
         if lead:
-            G = flat.shape[0]
-            return (flat[:, o1:o2].contiguous().view(torch.float32).view(G, T, N, A),
-                    flat[:, :o1].contiguous().view(torch.float64).view(G, T, N),
-                    flat[:, o2:].contiguous().view(torch.int32).view(G, T, N))
-        return (packed[o1:o2].view(torch.float32).view(T, N, A), packed[:o1].view(torch.float64).view(T, N),
-                packed[o2:].view(torch.int32).view(T, N))
+            flat = packed.reshape(-1, self._nbytes)
+            return flat[:, off:off + nb].contiguous().view(dt).view(flat.shape[0], rows, N, *trail)
+        return packed[off:off + nb].view(dt).view(rows, N, *trail)
+
+    def _typed(self, packed: torch.Tensor, lead: Tuple[int, ...] = ()):
+        """(actions, rewards, dones) views of a packed chunk (of G packed chunks when ``lead``)."""
+        return tuple(self._field(packed, k, lead) for k in ("actions", "rewards", "dones"))
+
+    def _typed_states(self, packed: torch.Tensor, lead: Tuple[int, ...] = ()):
+        """(obs_src, obs_pos) views of a packed chunk."""
+        return tuple(self._field(packed, k, lead) for k in ("obs_src", "obs_pos"))
 
     # the chunk being filled
     @property
@@ -79,6 +105,16 @@ class TrajectoryBuffer:
     @property
     def dones(self) -> torch.Tensor:
         return self._views[self._cur][2][:, : self.N]
+
+    @property
+    def obs_src(self) -> torch.Tensor:
+        """(T + 1, N) int64 window offsets of the stored states (``states=True``); row T = the last returned one."""
+        return self._state_views[self._cur][0][:, : self.N]
+
+    @property
+    def obs_pos(self) -> torch.Tensor:
+        """(T + 1, N, A) float64 position features of the stored states (``states=True``)."""
+        return self._state_views[self._cur][1][:, : self.N]
 
     @property
     def _packed(self) -> torch.Tensor:
@@ -97,6 +133,8 @@ class TrajectoryBuffer:
         return self.t >= self.T
 
     def clear(self) -> None:
+        if self.t == self.T:
+            self._carry_state(self._cur, self._cur)
         self.t = 0
 
     def store(self, actions: torch.Tensor, rewards: torch.Tensor, dones: torch.Tensor) -> None:
@@ -115,6 +153,62 @@ class TrajectoryBuffer:
             self.rewards[self.t].copy_(rewards)
             self.dones[self.t].copy_(dones)
         self.t += 1
+
+    def begin(self, env_or_descriptors) -> None:
+        """Row 0 of the state descriptors: the observation the policy is looking at when the chunk starts.  Pass the
+        env (``last_observation_descriptors()``: the current state after ``reset()``, else what the last step
+        recorded) or a ``(obs_src (N,), obs_pos (N, A))`` pair.  When a chunk follows another (``clear()`` /
+        ``all_gather_async()``) row 0 is carried over from the previous chunk's row T automatically."""
+        if not self.has_states:
+            raise RuntimeError("this TrajectoryBuffer was built without states=True")
+        if self.t != 0:
+            raise RuntimeError("begin() belongs at the start of a chunk")
+        src, pos = self._state_slots[self._cur][0]
+        d = env_or_descriptors if isinstance(env_or_descriptors, tuple) else env_or_descriptors.last_observation_descriptors()
+        if d[0].data_ptr() != src.data_ptr():
+            src.copy_(d[0].reshape(self.N))
+            pos.copy_(d[1].reshape(self.N, self.A))
+        self._begun = True
+
+    def state_slot(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        """``descriptors_out`` for the ``env.step`` that fills the slot ``next_slot()`` / ``store()`` just handed out:
+        row t of the state descriptors (t already advanced) = the observation that step returns = the state the
+        policy sees at step t (row T: the bootstrap state)."""
+        if not self.has_states:
+            raise RuntimeError("this TrajectoryBuffer was built without states=True")
+        if not getattr(self, "_begun", False):
+            raise RuntimeError("call begin(env) at the start of the first chunk: row 0 of the states is not set")
+        if self.t < 1:
+            raise RuntimeError("state_slot() follows next_slot() / store()")
+        return self._state_slots[self._cur][self.t]
+
+    def _carry_state(self, src_chunk: int, dst_chunk: int) -> None:
+        """Row T of a finished chunk is row 0 of the next one."""
+        if self.has_states and getattr(self, "_begun", False):
+            (s_from, p_from), (s_to, p_to) = self._state_slots[src_chunk][self.T], self._state_slots[dst_chunk][0]
+            if s_from.data_ptr() != s_to.data_ptr():
+                s_to.copy_(s_from)
+                p_to.copy_(p_from)
+
+    def states(self, env, t: int) -> torch.Tensor:
+        """The (N, W, 5A) observation the policy saw at step t of the chunk being filled (t = len(self): the one the
+        last step returned), rendered now."""
+        if not self.has_states:
+            raise RuntimeError("this TrajectoryBuffer was built without states=True")
+        if not 0 <= t <= self.t:
+            raise IndexError(f"step {t} is not filled (t = {self.t})")
+        src, pos = self._state_slots[self._cur][t]
+        return env.render(src, pos)
+
+    def minibatch_states(self, env, sample_indices: torch.Tensor) -> torch.Tensor:
+        """Observations (B, W, 5A) of the samples ``sample_indices`` of the filled part of the chunk, numbered as
+        the reference's buffer numbers them after ``reshape`` (buffer.py:102-109: sample = env * steps + step) --
+        what ``batch_states[mini_batch_indices]`` is in PPO_agent.py:182-186, rendered instead of stored."""
+        if not self.has_states:
+            raise RuntimeError("this TrajectoryBuffer was built without states=True")
+        idx = sample_indices.reshape(-1).to(device=self.device, dtype=torch.int64)
+        n, t = idx // self.t, idx % self.t
+        return env.render(self.obs_src[t, n], self.obs_pos[t, n])
 
     def next_slot(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
         """Zero-copy form of ``store``: views of slot t -- actions (N, A), rewards (N,), dones (N,) --
@@ -175,6 +269,8 @@ class TrajectoryBuffer:
                                                        async_op=True)
         self._cur = 1 - i
         self._wait(self._cur)  # the chunk about to be refilled must have left
+        if self.t == self.T:
+            self._carry_state(i, self._cur)
         self.t = 0
 
     def _wait(self, i: int) -> None:
@@ -182,13 +278,21 @@ class TrajectoryBuffer:
             self._pending[i].wait()  # stream-level wait for NCCL/RCCL; blocks the host only for gloo
             self._pending[i] = None
 
-    def wait_gathered(self):
-        """(actions, rewards, dones) of the most recently started gather, as (G, T, n, ...) tensors."""
+    def wait_gathered(self, with_states: bool = False):
+        """(actions, rewards, dones) of the most recently started gather, as (G, T, n, ...) tensors;
+        ``with_states=True`` appends (obs_src (G, T, n), obs_pos (G, T, n, A)) -- renderable on this rank with
+        ``env.render`` although they describe other ranks' envs."""
         i = 1 - self._cur
         self._wait(i)
         if self._gathered[i] is None:
             raise RuntimeError("no gather has been started")
-        return self._typed(self._gathered[i], lead=(self._gathered[i].shape[0],))
+        lead = (self._gathered[i].shape[0],)
+        out = self._typed(self._gathered[i], lead=lead)
+        if with_states:
+            if not self.has_states:
+                raise RuntimeError("this TrajectoryBuffer was built without states=True")
+            out = out + self._typed_states(self._gathered[i], lead=lead)
+        return out
 
     def drain(self) -> None:
         for i in (0, 1):

@@ -160,6 +160,26 @@ int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32
                           void *stream);
 
 /*
+ * fe_env_step that ALSO returns the observation it renders as descriptors -- obs_src_out (N) i64, obs_pos_out (N*A)
+ * f64, the pair fe_env_render / fe_env_render_n turn back into that observation (the terminal window on done steps,
+ * TSE:321, not the reset state fe_env_describe would describe).  These are the `next_states` of the reference's loop
+ * (examples/time_series/PPO_LSTM_training_SPY.py:26-28: states = next_states; agent.store(states, ...)), written
+ * straight into a trajectory slot: 8 + 8A bytes per env-step.
+ */
+int fe_env_step_described(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                          int64_t *obs_src_out, double *obs_pos_out, void *stream);
+
+/*
+ * fe_env_render for ANY number of descriptors: obs_src (count) i64, obs_pos (count*A) f64 -> obs (count, W, 5*A) in
+ * the env's observation dtype.  With fe_env_describe this is the `states` field of the reference's PPO buffer without
+ * its bytes: the buffer keeps every step's observation (finenvs/agents/PPO/buffer.py:33-56, one torch.cat per step;
+ * 40*W*A bytes per env-step) and training indexes minibatches out of it (finenvs/agents/PPO/PPO_agent.py:175-188);
+ * a trajectory of descriptors costs 8 + 8*A bytes per env-step and is rendered per minibatch -- on any rank, since the
+ * tables are replicated (finenvs_amd/trajectory.py, states=True).
+ */
+int fe_env_render_n(fe_env *env, const int64_t *obs_src, const double *obs_pos, int64_t count, void *obs, void *stream);
+
+/*
  * Table form of the in-kernel linear policy.  For fixed weights the log-return part of the policy
  * is an indicator of the day's series, like the reference's precomputed log-returns (TSE:179-194):
  * fe_policy_table fills table (D, L, A) f64 with

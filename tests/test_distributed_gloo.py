@@ -111,3 +111,67 @@ def test_shards_cover_days_like_the_single_process_env():
             lo, hi = shard_range(N, r, world)
             parts.append(np.arange(lo, hi) % D)
         assert np.array_equal(np.concatenate(parts), single)
+
+
+def _state_of(step, gidx):
+    """Deterministic descriptors per (row, global env): row t = the state at step t, row T = the bootstrap state."""
+    src = (gidx.long() * 100 + step * 4)
+    pos = (gidx.unsqueeze(1) * 0.25 + torch.arange(A) + step).double()
+    return src, pos
+
+
+def _states_worker(rank, world, port, q, N_TOTAL):
+    CAP = (N_TOTAL + world - 1) // world
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_range(N_TOTAL, rank, world)
+        n = hi - lo
+        gidx = torch.arange(lo, lo + n, dtype=torch.float64)
+        buf = TrajectoryBuffer(T, n, A, device="cpu", host_rehearsal=True, capacity=CAP, states=True)
+        ok = True
+        for chunk in range(2):
+            if chunk == 0:
+                buf.begin(_state_of(0, gidx))
+            for t in range(T):
+                a, r, d = buf.next_slot()
+                a.fill_(float(t)); r.fill_(float(chunk)); d.zero_()
+                src, pos = buf.state_slot()  # what env.step(descriptors_out=...) would fill
+                s2, p2 = _state_of(chunk * T + t + 1, gidx)
+                src.copy_(s2); pos.copy_(p2)
+            buf.all_gather_async()
+            a_g, r_g, d_g, src_g, pos_g = buf.wait_gathered(with_states=True)
+            ok &= tuple(src_g.shape) == (world, T + 1, CAP) and tuple(pos_g.shape) == (world, T + 1, CAP, A)
+            for rr in range(world):
+                l2, h2 = shard_range(N_TOTAL, rr, world)
+                g2 = torch.arange(l2, h2, dtype=torch.float64)
+                for row in range(T + 1):  # every rank holds every rank's states, rows 0..T of this chunk
+                    s2, p2 = _state_of(chunk * T + row, g2)
+                    ok &= torch.equal(src_g[rr, row, : h2 - l2], s2) and torch.equal(pos_g[rr, row, : h2 - l2], p2)
+            # the chunk now being filled starts from the previous chunk's bootstrap row
+            s0, p0 = _state_of((chunk + 1) * T, gidx)
+            ok &= torch.equal(buf.obs_src[0], s0) and torch.equal(buf.obs_pos[0], p0)
+        joined = TrajectoryBuffer.join_shards(src_g, N_TOTAL)
+        ok &= tuple(joined.shape) == (T + 1, N_TOTAL)
+        buf.drain()
+        q.put((rank, bool(ok)))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_state_descriptors_travel_with_the_all_gather_gloo():
+    """states=True: the gathered chunk carries every rank's state descriptors (rows 0..T), and a chunk that follows
+    another starts from its bootstrap row."""
+    world, n_total = 2, 15
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_states_worker, args=(r, world, port, q, n_total)) for r in range(world)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(180)
+        assert p.exitcode == 0
+    got = sorted(q.get(timeout=5) for _ in range(world))
+    assert got == [(r, True) for r in range(world)]
