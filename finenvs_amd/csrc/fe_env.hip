@@ -1617,6 +1617,12 @@ struct LstmArgs {
     float *actions_out;
     double *rew_out;
     int32_t *done_out;
+    // training rollouts (PPO_agent.py:98-108): actions = clamp(mean + std * noise, -1, 1), the eval env acts on the mean
+    const float *noise;  // (K, N*A) standard normal draws, or null: act on the mean
+    float std;
+    float *means_out;    // (K, N*A) or null
+    int64_t *traj_src;   // (K + 1, N) or null: descriptors of the state the policy sees at every step (+ the last one)
+    double *traj_pos;    // (K + 1, N*A)
 };
 
 template <int NT> struct LstmGeom {
@@ -1766,8 +1772,13 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
             st.lng = p.lng[sl];
             st.sht = p.sht[sl];
             st.margin = p.margin[sl];
+            const double pos0 = r.obs_pos[sl];
+            l.pos[e * A + a] = pos0;
             if (a == 0) l.src[e] = r.obs_src[n];
-            l.pos[e * A + a] = r.obs_pos[sl];
+            if (r.traj_src) {  // row 0: the state the first policy evaluation sees
+                r.traj_pos[sl] = pos0;
+                if (a == 0) r.traj_src[n] = r.obs_src[n];
+            }
         }
         __syncthreads();  // also covers s_wout on the first tile
         const int pairs = ebt * A;
@@ -1882,10 +1893,20 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
 #pragma unroll 8
                 for (int u = 0; u < H; ++u) o = fmaf(s_wout[u], hl[u], o);
                 act = r.out_act == 0 ? lstm_tanh(o) : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o));
+                if (r.means_out) r.means_out[(int64_t)k * NA + sl] = act;
+                if (r.noise && n != p.eval_env) {  // distribution.sample() clamped; the eval env keeps the mean
+                    const float dev = r.std * r.noise[(int64_t)k * NA + sl];
+                    const float smp = act + dev;
+                    act = smp < -1.0f ? -1.0f : (smp > 1.0f ? 1.0f : smp);
+                }
                 if (r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
             }
             account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
                                  r.done_out + (int64_t)k * p.N);
+            if (active && r.traj_src) {  // row k + 1: the observation this step returns (own LDS entries: no barrier needed)
+                r.traj_pos[(int64_t)(k + 1) * NA + sl] = l.pos[e * A + a];
+                if (a == 0) r.traj_src[(int64_t)(k + 1) * p.N + n] = l.src[e];
+            }
             lds_barrier();  // the new observation's descriptors are complete; everyone is done with h_W
         }
         if (active) {  // state and descriptors go back to HBM once per launch
@@ -2564,7 +2585,11 @@ int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, c
 
 int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout,
                         float bout, int32_t H, int32_t out_activation, int32_t K, int64_t *obs_src, double *obs_pos,
-                        float *actions_out, double *rewards_out, int32_t *dones_out, void *stream) {
+                        const float *noise, float std, float *actions_out, float *means_out, double *rewards_out,
+                        int32_t *dones_out, int64_t *states_src_out, double *states_pos_out, void *stream) {
+    if ((states_src_out == nullptr) != (states_pos_out == nullptr))
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: states_src_out and states_pos_out go together");
+    if (noise && !(std >= 0.0f)) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: std must be >= 0 when noise is given");
     if (!env || !logret_f32 || !whh || !wx || !wout || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
         return fail(FE_ERR_ARG, "fe_env_rollout_lstm: bad argument");
     if (H != 32 && H != 64 && H != 128) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: H must be 32, 64 or 128 (got %d)", (int)H);
@@ -2576,6 +2601,7 @@ int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, 
     LstmArgs r;
     r.lr32 = logret_f32; r.whh = whh; r.wx = wx; r.wout = wout; r.bout = bout; r.H = H; r.out_act = out_activation; r.K = K;
     r.obs_src = obs_src; r.obs_pos = obs_pos; r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
+    r.noise = noise; r.std = std; r.means_out = means_out; r.traj_src = states_src_out; r.traj_pos = states_pos_out;
     // SP (env, asset) pairs per workgroup: 2 (H = 128) or 4 column tiles of 32; an env's sleeves stay together
     const int SP = H == 128 ? LstmGeom<4>::SP : LstmGeom<2>::SP;
     if (p.A > SP)

@@ -342,19 +342,51 @@ class FusedLSTMRollout(_FusedEvaluation):
         _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
                                                  self.env._stream()))
 
-    def run(self, num_steps: int, record_actions: bool = True):
-        """Returns (actions (K, N, A) f32 or None, rewards (K, N) f64, dones (K, N) int32)."""
+    def run(self, num_steps: int, record_actions: bool = True, noise: Optional[torch.Tensor] = None,
+            std: Optional[float] = None, record_means: bool = False, trajectory=None):
+        """Returns (actions (K, N, A) f32 or None, rewards (K, N) f64, dones (K, N) int32).
+
+        Training rollouts (``agent.step`` of finenvs/agents/PPO/PPO_agent.py:98-108): pass ``noise`` -- (K, N, A) f32
+        standard-normal draws from the caller's generator -- and ``std = exp(log_standard_deviation)``; the action is
+        ``clamp(mean + std * noise, -1, 1)``, the eval env of a training-mode env acts on the mean.  ``record_means``
+        keeps the means in ``self.means`` ((K, N, A), what ``log_prob`` needs).  ``trajectory``: an empty
+        ``TrajectoryBuffer(K, N, A, states=True)`` without capacity padding -- the kernel writes actions, rewards,
+        dones and the K + 1 state descriptors straight into its chunk (``agent.store`` for K steps at once; the
+        returned tensors are then views of it)."""
         from . import _lib
 
         env, K = self.env, int(num_steps)
         N, A = env.num_envs, env.num_assets
-        actions = torch.empty((K, N, A), dtype=torch.float32, device=env._dev) if record_actions else None
-        rewards = torch.empty((K, N), dtype=torch.float64, device=env._dev)
-        dones = torch.empty((K, N), dtype=torch.int32, device=env._dev)
+        dev = env._dev
+        src_out = pos_out = None
+        if trajectory is not None:
+            tr = trajectory
+            if not (tr.has_states and tr.T == K and tr.N == N and tr.C == N and tr.A == A and len(tr) == 0 and tr.device == dev):
+                raise ValueError("trajectory must be an empty TrajectoryBuffer(K, N, A, states=True) on the env's device "
+                                 "without capacity padding")
+            actions, rewards, dones = tr.actions, tr.rewards, tr.dones
+            src_out, pos_out = tr.obs_src, tr.obs_pos
+        else:
+            actions = torch.empty((K, N, A), dtype=torch.float32, device=dev) if record_actions else None
+            rewards = torch.empty((K, N), dtype=torch.float64, device=dev)
+            dones = torch.empty((K, N), dtype=torch.int32, device=dev)
+        if noise is not None:
+            if std is None or not float(std) >= 0.0:
+                raise ValueError("noise needs std >= 0 (= exp(log_standard_deviation))")
+            if noise.dtype is not torch.float32 or noise.numel() != K * N * A or noise.device != dev:
+                raise ValueError(f"noise must be ({K}, {N}, {A}) float32 on {dev}")
+            noise = noise.contiguous()
+        self.means = torch.empty((K, N, A), dtype=torch.float32, device=dev) if record_means else None
         _lib.check(env._lib.fe_env_rollout_lstm(
             env._handle, self._lr32.data_ptr(), self.whh.data_ptr(), self.wx.data_ptr(), self.wout.data_ptr(), self.bout,
             self.H, self.out_act, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
-            actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
+            noise.data_ptr() if noise is not None else None, float(std) if noise is not None else 0.0,
+            actions.data_ptr() if actions is not None else None, self.means.data_ptr() if record_means else None,
+            rewards.data_ptr(), dones.data_ptr(), src_out.data_ptr() if src_out is not None else None,
+            pos_out.data_ptr() if pos_out is not None else None, env._stream()))
+        if trajectory is not None:
+            trajectory.t = K
+            trajectory._begun = True
         return actions, rewards, dones
 
     def observation(self) -> torch.Tensor:

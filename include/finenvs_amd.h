@@ -227,11 +227,19 @@ int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, c
  *   of hidden unit 8*mt + 4*half + b;  wx (4H, 8) f32, same row order: weight_ih_l0[row][0..4], bias_ih + bias_hh,
  *   0, 0;  wout (H), bout: the output layer;  H in {32, 64, 128};  out_activation 0 = tanh, 1 = clamp to [-1, 1].
  * A (assets per env) must not exceed the pairs of a workgroup tile (64 for H = 128, else 128): FE_ERR_ARG.
+ * Training rollouts (finenvs/agents/PPO/PPO_agent.py:98-108, agent.step): with noise (K, N*A) f32 standard-normal
+ * draws (made by the caller's generator) and std = exp(log_standard_deviation), the action is
+ * clamp(mean + std * noise, -1, 1) (one f32 product, one f32 sum) -- except for the eval env of a training-mode env,
+ * which acts on the mean (PPO_agent.py:105-107); means_out (K, N*A) receives the means (for log_prob), and
+ * states_src_out (K+1, N) i64 / states_pos_out (K+1, N*A) f64 the descriptors of the state the policy saw at every
+ * step (row k) and of the last returned one (row K) -- the `states` of agent.store (PPO_LSTM_training_SPY.py:27),
+ * see fe_env_render_n.  noise / means_out / states_*_out may be NULL.
  * Other arguments, loop semantics and side effects as fe_env_rollout_linear.
  */
 int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout,
                         float bout, int32_t H, int32_t out_activation, int32_t K, int64_t *obs_src, double *obs_pos,
-                        float *actions_out, double *rewards_out, int32_t *dones_out, void *stream);
+                        const float *noise, float std, float *actions_out, float *means_out, double *rewards_out,
+                        int32_t *dones_out, int64_t *states_src_out, double *states_pos_out, void *stream);
 
 /* Diagnostics: the sigmoid and tanh fe_env_rollout_lstm applies to nn.LSTM's gates (finenvs/agents/networks/lstm.py:28-34)
  * and to the actor's output (continuous_actor.py:112), elementwise on n device floats: pins them against the oracle. */

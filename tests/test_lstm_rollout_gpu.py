@@ -213,3 +213,56 @@ def test_lstm_evaluation_loop_returns_match_stepwise_oracle(fe, fo):
             break
     assert want is not None
     assert_bits(got, want, "episode returns")
+
+
+@pytest.mark.parametrize("N,A,W,H", [(150, 1, 4, 64), (45, 3, 5, 32)])
+def test_lstm_training_rollout_samples_and_fills_the_trajectory(fe, fo, N, A, W, H):
+    """The K-step form of the reference's TRAINING loop (PPO_LSTM_training_SPY.py:22-28 with agent.step of
+    PPO_agent.py:98-108): actions = clamp(mean + std * noise), the eval env (last env, training mode) acts on the mean,
+    and agent.store's fields -- states as descriptors, actions, rewards, dones -- land in the trajectory chunk.
+    Everything equals the oracle stepped one action at a time, bit for bit; the stored states render to the
+    observations the oracle's policy saw."""
+    from finenvs_amd.rollout import FusedLSTMRollout
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    ref, env = _make(fe, fo, N, A, W, 6, 40, 0.05, False, seed=N + H)
+    assert env._eval_env == N - 1  # training mode: the last env is the evaluation env
+    lstm, lin = _modules(H, seed=H)
+    whh, wx, wout, bout = _packed(fo, lstm, lin)
+    roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    K, std = 12, np.float32(0.6)
+    traj = TrajectoryBuffer(K, N, A, states=True)
+    g = torch.Generator(device="cuda").manual_seed(11)
+    obs = ref.reset().copy()
+    sampled_beyond_clamp = 0
+    for chunk in range(8):
+        noise = torch.randn((K, N, A), generator=g, device="cuda")
+        acts, rews, dones = roll.run(K, noise=noise, std=float(std), record_means=True, trajectory=traj)
+        assert acts.data_ptr() == traj.actions.data_ptr() and len(traj) == K and traj.full()
+        z = t2n(noise)
+        for k in range(K):
+            mean = fo.policy_lstm(obs, whh, wx, wout, bout)
+            a_ref = np.clip((mean + (std * z[k]).astype(np.float32)).astype(np.float32), np.float32(-1), np.float32(1))
+            a_ref[N - 1] = mean[N - 1]
+            sampled_beyond_clamp += int((np.abs(mean + std * z[k]) > 1).sum())
+            what = f"chunk {chunk} step {k}"
+            assert_bits(t2n(roll.means[k]), mean, what + " means")
+            assert_bits(t2n(acts[k]), a_ref, what + " actions")
+            want_state = obs
+            assert_bits(t2n(traj.states(env, k)), want_state, what + " stored state")
+            obs, r_ref, d_ref, _ = ref.step(a_ref)
+            obs = obs.copy()
+            assert_bits(t2n(rews[k]), r_ref, what + " rewards")
+            assert_bits(t2n(dones[k]), d_ref, what + " dones")
+        assert_bits(t2n(traj.states(env, K)), obs, f"chunk {chunk} bootstrap state")
+        assert_bits(t2n(env.cash), ref.cash, f"chunk {chunk} cash")
+        assert_bits(t2n(env.env_indices), ref.env_idx, f"chunk {chunk} env_idx")
+        traj.clear()
+    assert sampled_beyond_clamp > 0  # the clamp of the sample was exercised
+    # log_prob as the agent computes it (PPO_agent.py:108) needs nothing but what the rollout returned
+    lp = torch.distributions.Normal(roll.means, float(std)).log_prob(acts)
+    assert torch.isfinite(lp).all()
+    with pytest.raises(ValueError):
+        roll.run(K, noise=torch.randn((K, N, A), device="cuda"))  # std missing
+    with pytest.raises(ValueError):
+        roll.run(K + 1, trajectory=traj)  # wrong length
