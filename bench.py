@@ -223,12 +223,18 @@ class Dist:
         torch.cuda.set_device(self.local_rank)
         self.dev = f"cuda:{self.local_rank}"
         self.dist = None
-        if self.world > 1:
+        # rehearsal knob (never set by the driver): run the N > 1 code path -- RCCL process group, trajectory all-gather
+        # legs, config-5 shard -- with the ONE rank a one-GPU box allows
+        self.multi = self.world > 1 or os.environ.get("FE_BENCH_FORCE_DIST") == "1"
+        if self.multi:
             import datetime
 
             import torch.distributed as dist
 
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
             kw = {"timeout": datetime.timedelta(minutes=5)}
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device(self.dev), **kw)
@@ -290,20 +296,18 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         N = env.num_envs
         g = torch.Generator(device=dev).manual_seed(7 + rank)
         actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
-        # Compact trajectory fields live in a device buffer; the step kernel writes rewards/dones
-        # straight into slot t and the "policy" (the pre-generated action ring) owns the action slots,
-        # so storing a step costs nothing extra.  With N > 1 a chunk is `steps` slots long (capped by memory), i.e.
+        # Compact trajectory fields live in a device buffer; the step kernel writes rewards, dones and its copy of the
+        # actions straight into slot t (fe_env_step_traj), so storing a step costs no extra launch.  (Round 2 found the
+        # earlier scheme -- actions pre-stored in the slots -- to read 256 KB of COLD memory per step once a chunk is longer
+        # than a few slots: +11 us per 30 us step at 64k envs, tools/cold_slots.py; a policy's output is hot.)  With N > 1 a chunk is `steps` slots long (capped by memory), i.e.
         # one timed block fills exactly one chunk, and the chunk filled by a block is all-gathered asynchronously
         # at the first step of the NEXT block: every timed block contains one whole all-gather (issued at its
         # start, drained by the fence at its end) that has the block's own steps to hide behind.
         T = TRAJ_T
-        if world > 1:
+        if D.multi:
             per_step = N * (8 + 4 * A + 4)
             T = max(1, min(steps, int(TRAJ_BUDGET // (per_step * (2 + 2 * world)))))
         traj = TrajectoryBuffer(T, N, A, device=dev)
-        for chunk in traj._views:  # slot t of either chunk holds ring[t % 8] (any valid actions will do)
-            for t in range(T):
-                chunk[0][t].copy_(actions[t % 8])
         torch.cuda.synchronize()
     except Exception as exc:  # noqa: BLE001  (allocation / construction: before any collective)
         err = f"{type(exc).__name__}: {exc}"
@@ -313,7 +317,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         torch.cuda.empty_cache()
         return {"workload": name, "config": config, "error": err or "another rank failed to build this workload"}
 
-    gather = [world > 1]  # mutable: the timed legs flip it
+    gather = [D.multi]  # mutable: the timed legs flip it
 
     def one_step(i):
         if traj.full():  # checked at the START of a step: a chunk completed by a block goes out with the next block
@@ -321,13 +325,15 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
                 traj.all_gather_async()  # overlaps the following steps; waited for before its chunk is reused
             else:
                 traj.clear()
+        # the "policy" hands over its output buffer (a ring of 8 pre-generated action tensors: hot, as a policy's fresh
+        # output is); agent.store's fields -- actions, rewards, dones -- are written into slot t by the step kernel itself
         a, r, d = traj.next_slot()
-        obs, rew, done, _ = env.step(a, rewards_out=r, dones_out=d)
+        obs, rew, done, _ = env.step(actions[i % 8], rewards_out=r, dones_out=d, actions_out=a)
         return obs
 
     roll = None
     if args.graph:
-        if world > 1 or steps % 8:
+        if D.multi or steps % 8:
             sys.exit("--graph: single GPU only, and --steps must be a multiple of 8")
         warmup = (warmup + 7) // 8 * 8
         from finenvs_amd.rollout import GraphedRollout
@@ -344,14 +350,24 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         D.barrier()
         torch.cuda.synchronize()
 
+    trace = os.environ.get("FE_BENCH_TRACE") == "1"  # stderr: where a timed block's wall time goes (host issue / drain / fence)
+
     def timed_blocks(r):
         out = []
         for _ in range(r):
             fence()
             t0 = time.perf_counter()
             run_steps(steps)
+            if trace:
+                t1 = time.perf_counter()
+                torch.cuda.synchronize()
+                t2 = time.perf_counter()
             fence()
             out.append(D.max_over_ranks(time.perf_counter() - t0))
+            if trace and rank == 0:
+                t3 = time.perf_counter()
+                print(f"[trace] issue {(t1 - t0) * 1e6:8.1f} us  drain {(t2 - t1) * 1e6:8.1f} us  fence+max {(t3 - t2) * 1e6:8.1f} us  "
+                      f"({steps} steps)", file=sys.stderr, flush=True)
         return out
 
     run_steps(warmup)
@@ -362,7 +378,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     est = D.max_over_ranks(time.perf_counter() - t0) / min(steps, 8)
     R = auto_repeats(repeats, steps, est)
     legs = {}
-    if world > 1:
+    if D.multi:
         gather[0] = True
         fence()
         traj.clear()
@@ -436,7 +452,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             "achieved_wall": Bh * N / (block / steps) / 1e9,
         },
     }
-    if world > 1:
+    if D.multi:
         res["multi_gpu"] = {
             "ranks_seen": D.dist.get_world_size(), "collective_backend": D.backend,
             "trajectory_slots": T, "all_gather_every_steps": T,
@@ -533,14 +549,20 @@ def main():
         pmc_child(args)
         return
 
+    # fd 1 carries ONE JSON line.  Native libraries write to stdout too -- RCCL printf()s a five-line version banner at
+    # communicator init -- so fd 1 points at stderr for the life of the process and the real stdout is kept for the result.
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+
     D = Dist(args)
     head = run_workload(args.config, args, D, args.steps, args.warmup, args.repeats,
-                        with_cpu=(not args.no_cpu and D.world == 1))
+                        with_cpu=(not args.no_cpu and not D.multi))
     if "error" in head:
         sys.exit(f"bench.py: headline workload failed: {head['error']}")
     def measure_traffic(res, config):
         """roofline.traffic measured live (the workload's env is gone by now: the children have the card to themselves)."""
-        if D.world != 1 or args.no_pmc or args.graph or "error" in res:
+        if D.multi or args.no_pmc or args.graph or "error" in res:
             return
         t, src = live_pmc_traffic(config, args.obs_f32, args.redraw, args.no_audition)
         if t is not None:
@@ -551,7 +573,7 @@ def main():
     measure_traffic(head, args.config)
     extras = []
     if not args.no_extra and not args.graph and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
-        wanted = ([3, 4] if D.world == 1 else [5])
+        wanted = ([3, 4] if not D.multi else [5])
         for c in wanted:
             if c == args.config:
                 continue
@@ -564,7 +586,7 @@ def main():
                 break
 
     fused = None
-    if D.world == 1 and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
+    if not D.multi and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
         fused = fused_rollout_legs(args)
 
     if D.rank == 0:
@@ -594,7 +616,7 @@ def main():
             "extra_configs": [{k: v for k, v in e.items() if k != "cpu_baseline"} for e in extras],
             "fused_rollouts": fused,
         }
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=result_out, flush=True)
     if D.dist is not None:
         D.barrier()
         D.dist.destroy_process_group()

@@ -46,7 +46,7 @@ SIGNATURES = {
     "fe_env_describe": (C.c_int, [_vp, _vp, _vp, _vp]),
     "fe_env_render": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "fe_env_render_n": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
-    "fe_env_step_described": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fe_env_step_traj": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_env_rollout_linear": (C.c_int, [_vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_policy_table": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "fe_env_rollout_table": (C.c_int, [_vp, _vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),

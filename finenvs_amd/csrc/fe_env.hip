@@ -171,8 +171,9 @@ struct Params {
     void *obs;
     double *rew;
     int32_t *done;
-    int64_t *desc_src;   // optional (fe_env_step_described): descriptors of the observation this step returns
+    int64_t *desc_src;   // optional (fe_env_step_traj): descriptors of the observation this step returns
     double *desc_pos;
+    float *act_store;    // optional (fe_env_step_traj): the actions, copied into a trajectory slot
     int64_t N, D, L;
     int64_t num_tiles;
     int64_t eval_env;
@@ -486,6 +487,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             p.desc_pos[sl] = s.pos_obs;
             if (a == 0) p.desc_src[n] = l.src[e];
         }
+        if (p.act_store) p.act_store[sl] = action;  // agent.store's `actions` field, no copy kernel
 #endif
     }
     // ---------------- phase 1b: one lane per env ----------------
@@ -745,7 +747,8 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
 // next one, indices of the one after.
 struct PipeState {
     SleeveIn in_cur, in_nxt;
-    float action_cur, action_nxt;
+    float action_cur, action_nxt, action_nn;  // actions run TWO tiles ahead: a caller's action buffer may be cold (a new
+                                              // trajectory slot every step costs a TLB walk + an HBM round trip, ~5 us)
     int64_t n_cur, n_nxt, n_nn, idx1, spot1, idx2, spot2;
     bool act0, act1, act2;
     unsigned long long t_accounted;  // FE_STAMP builds
@@ -757,6 +760,12 @@ __device__ __forceinline__ int64_t pipe_env_of(const Params &p, int EB, int e, i
     act = t < p.num_tiles && (int64_t)e < (left < (int64_t)EB ? left : (int64_t)EB);
     return n0 + e;
 }
+
+// Actions are fetched two tiles ahead with f64 observations (measured on a shared ring, tools/ab_step.py: -2.6 % with hot
+// action buffers, 41.1 -> 37.8 us/step with cold ones, tools/cold_slots.py); with f32 observations the extra live
+// register spills at the 6 workgroups per CU that shape wants (+2.7 %), so f32 keeps one tile ahead.
+template <typename OT>
+constexpr bool kActionsTwoAhead = sizeof(OT) == 8;
 
 // One tile of the single-asset pipeline: account it (inputs already in registers), prefetch the next tile's body and
 // the head of the one after, stream its observation.  FIRST: the workgroup's first tile, whose first phase-2
@@ -773,14 +782,18 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
 #endif
     // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
     load_body(p, 1, 0, ps.act1, ps.n_nxt, ps.idx1, ps.spot1, ps.in_nxt);
-    if (ps.act1) ps.action_nxt = p.actions[ps.n_nxt];
+    if constexpr (!kActionsTwoAhead<OT>)
+        if (ps.act1) ps.action_nxt = p.actions[ps.n_nxt];
     ps.n_nn = pipe_env_of(p, EB, e, tile + 2 * G, ps.act2);
     load_head(p, ps.act2, ps.n_nn, ps.idx2, ps.spot2);
+    if constexpr (kActionsTwoAhead<OT>)
+        if (ps.act2) ps.action_nn = p.actions[ps.n_nn];
     stream_tile<OT, VEC, true>(p, l, stage, 1, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave,
                                kBlock / 64, FIRST && kHoistFirst<OT>, pre);
     tile_barrier();  // LDS is reused by the next tile
     ps.in_cur = ps.in_nxt;
     ps.action_cur = ps.action_nxt;
+    if constexpr (kActionsTwoAhead<OT>) ps.action_nxt = ps.action_nn;
     ps.n_cur = ps.n_nxt; ps.act0 = ps.act1;
     ps.n_nxt = ps.n_nn; ps.act1 = ps.act2;
     ps.idx1 = ps.idx2; ps.spot1 = ps.spot2;
@@ -914,7 +927,7 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
         }
 #endif
         PipeState ps;
-        ps.action_cur = 0.0f; ps.action_nxt = 0.0f;
+        ps.action_cur = 0.0f; ps.action_nxt = 0.0f; ps.action_nn = 0.0f;
         ps.n_cur = pipe_env_of(p, EB, e, tile, ps.act0);
         ps.n_nxt = pipe_env_of(p, EB, e, tile + G, ps.act1);
         // first tile: everything that needs no index goes out with the index loads (one round trip), only the
@@ -922,6 +935,8 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
         load_head(p, ps.act0, ps.n_cur, ps.idx1, ps.spot1);
         load_state(p, ps.act0, ps.n_cur, ps.in_cur);
         if (ps.act0) ps.action_cur = p.actions[ps.n_cur];
+        if constexpr (kActionsTwoAhead<OT>)
+            if (ps.act1) ps.action_nxt = p.actions[ps.n_nxt];  // the second tile's action leaves with the first one's
 #if FE_STAMP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (stamps && tid == 0) stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
@@ -2136,7 +2151,7 @@ static const void *kernel_for(bool f32, int vec, bool single) {
 // modified by reset/step, so concurrent calls on different streams do not race on the host side.
 template <bool RESET_ONLY>
 static int launch_env(const fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
-                      hipStream_t st, int64_t *desc_src = nullptr, double *desc_pos = nullptr) {
+                      hipStream_t st, int64_t *desc_src = nullptr, double *desc_pos = nullptr, float *act_store = nullptr) {
     Params p = env->p;
     p.actions = actions;
     p.obs = obs;
@@ -2144,6 +2159,7 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     p.done = dones;
     p.desc_src = desc_src;
     p.desc_pos = desc_pos;
+    p.act_store = act_store;
     void *args[] = {&p};
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
@@ -2400,12 +2416,14 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
     return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream);
 }
 
-int fe_env_step_described(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
-                          int64_t *obs_src_out, double *obs_pos_out, void *stream) {
-    if (!env || !actions || !obs || !rewards || !dones || !obs_src_out || !obs_pos_out)
-        return fail(FE_ERR_ARG, "fe_env_step_described: null argument");
-    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step_described: state not bound");
-    return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream, obs_src_out, obs_pos_out);
+int fe_env_step_traj(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                     float *actions_store_out, int64_t *obs_src_out, double *obs_pos_out, void *stream) {
+    if (!env || !actions || !obs || !rewards || !dones) return fail(FE_ERR_ARG, "fe_env_step_traj: null argument");
+    if ((obs_src_out == nullptr) != (obs_pos_out == nullptr))
+        return fail(FE_ERR_ARG, "fe_env_step_traj: obs_src_out and obs_pos_out go together");
+    if (actions_store_out == actions) actions_store_out = nullptr;  // already where they belong
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step_traj: state not bound");
+    return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream, obs_src_out, obs_pos_out, actions_store_out);
 }
 
 int fe_env_describe(fe_env *env, int64_t *obs_src, double *obs_pos, void *stream) {

@@ -412,14 +412,17 @@ class TimeSeriesEnv:
 
     def step(self, actions: torch.Tensor, rewards_out: Optional[torch.Tensor] = None,
              dones_out: Optional[torch.Tensor] = None,
-             descriptors_out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None
+             descriptors_out: Optional[Tuple[torch.Tensor, torch.Tensor]] = None,
+             actions_out: Optional[torch.Tensor] = None
              ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, dict]:
         """One fused launch of TSE:277-296.  Returns (obs (N,W,5A), rewards (N,) f64,
         dones (N,) int32, info).  ``rewards_out`` / ``dones_out`` let the kernel write straight into
         caller-owned storage (e.g. a TrajectoryBuffer slot) instead of fresh tensors;
         ``descriptors_out = (obs_src (N,) int64, obs_pos (N, A) float64)`` additionally receives the returned
         observation as descriptors (``render`` turns them back into it): the ``next_states`` of the reference's loop
-        for a trajectory that keeps states without their bytes (``TrajectoryBuffer(states=True).state_slot()``)."""
+        for a trajectory that keeps states without their bytes (``TrajectoryBuffer(states=True).state_slot()``);
+        ``actions_out`` (N, A) f32 receives a copy of the actions -- ``agent.store``'s action field written by the kernel
+        that reads the actions anyway, so the policy's output can stay where the policy wrote it."""
         N, A = self.num_envs, self.num_assets
         if actions.dtype is not torch.float32:
             actions = actions.float()  # the reference's in-repo callers all pass f32 (SURVEY App. A iii)
@@ -440,16 +443,23 @@ class TimeSeriesEnv:
             dones = dones_out
             if dones.dtype is not torch.int32 or dones.numel() != N or not dones.is_contiguous() or dones.device != self._dev:
                 raise ValueError("dones_out must be a contiguous int32 tensor of num_envs elements on the env's device")
-        if descriptors_out is None:
+        if descriptors_out is None and actions_out is None:
             rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
                                self._stream())
         else:
-            src, pos = descriptors_out
-            for t, count, dt in ((src, N, torch.int64), (pos, N * A, torch.float64)):
-                if t.dtype is not dt or t.numel() != count or not t.is_contiguous() or t.device != self._dev:
-                    raise ValueError("descriptors_out must be contiguous (int64 (N,), float64 (N, A)) tensors on the env's device")
-            rc = self._lib.fe_env_step_described(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
-                                                 dones.data_ptr(), src.data_ptr(), pos.data_ptr(), self._stream())
+            src = pos = None
+            if descriptors_out is not None:
+                src, pos = descriptors_out
+                for t, count, dt in ((src, N, torch.int64), (pos, N * A, torch.float64)):
+                    if t.dtype is not dt or t.numel() != count or not t.is_contiguous() or t.device != self._dev:
+                        raise ValueError("descriptors_out must be contiguous (int64 (N,), float64 (N, A)) tensors on the env's device")
+            if actions_out is not None and (actions_out.dtype is not torch.float32 or actions_out.numel() != N * A
+                                            or not actions_out.is_contiguous() or actions_out.device != self._dev):
+                raise ValueError("actions_out must be a contiguous float32 tensor of num_envs x num_assets elements on the env's device")
+            rc = self._lib.fe_env_step_traj(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
+                                            actions_out.data_ptr() if actions_out is not None else None,
+                                            src.data_ptr() if src is not None else None,
+                                            pos.data_ptr() if pos is not None else None, self._stream())
         self._last_descriptors = descriptors_out  # None: the observation just returned was not recorded
         self._stepped = True
         if rc != 0:

@@ -160,14 +160,18 @@ int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32
                           void *stream);
 
 /*
- * fe_env_step that ALSO returns the observation it renders as descriptors -- obs_src_out (N) i64, obs_pos_out (N*A)
- * f64, the pair fe_env_render / fe_env_render_n turn back into that observation (the terminal window on done steps,
- * TSE:321, not the reset state fe_env_describe would describe).  These are the `next_states` of the reference's loop
- * (examples/time_series/PPO_LSTM_training_SPY.py:26-28: states = next_states; agent.store(states, ...)), written
- * straight into a trajectory slot: 8 + 8A bytes per env-step.
+ * fe_env_step that ALSO writes the trajectory fields a rollout loop keeps per step
+ * (examples/time_series/PPO_LSTM_training_SPY.py:26-28: agent.store(states, actions, ...); states = next_states;
+ * finenvs/agents/PPO/buffer.py:33-56), each optional (NULL):
+ *   actions_store_out (N*A) f32: a copy of `actions` -- the policy's output stays where the policy wrote it (hot), the
+ *     trajectory slot gets its copy from the kernel that reads it anyway (no copy launch);
+ *   obs_src_out (N) i64 + obs_pos_out (N*A) f64 (together): the observation this step returns as descriptors, the pair
+ *     fe_env_render / fe_env_render_n turn back into it (the terminal window on done steps, TSE:321, not the reset state
+ *     fe_env_describe would describe): 8 + 8A bytes per env-step for the `states` field.
+ * rewards / dones may point into the trajectory as with fe_env_step.
  */
-int fe_env_step_described(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
-                          int64_t *obs_src_out, double *obs_pos_out, void *stream);
+int fe_env_step_traj(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                     float *actions_store_out, int64_t *obs_src_out, double *obs_pos_out, void *stream);
 
 /*
  * fe_env_render for ANY number of descriptors: obs_src (count) i64, obs_pos (count*A) f64 -> obs (count, W, 5*A) in

@@ -2,7 +2,7 @@
 
 The reference's buffer stores every step's observation (finenvs/agents/PPO/buffer.py:33-56) and training indexes
 minibatches out of it (PPO_agent.py:175-188).  ``TrajectoryBuffer(states=True)`` stores 8 + 8A bytes per env-step
-instead -- written by the step kernel itself (fe_env_step_described) -- and renders on demand; every rendered state
+instead -- written by the step kernel itself (fe_env_step_traj) -- and renders on demand; every rendered state
 must equal, bit for bit, the observation the loop actually fed to the policy, including terminal windows on done
 steps and the bootstrap state after the last step, and the oracle's observation at the same step.
 """
