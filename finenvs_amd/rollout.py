@@ -385,8 +385,7 @@ class FusedLSTMRollout(_FusedEvaluation):
             rewards.data_ptr(), dones.data_ptr(), src_out.data_ptr() if src_out is not None else None,
             pos_out.data_ptr() if pos_out is not None else None, env._stream()))
         if trajectory is not None:
-            trajectory.t = K
-            trajectory._begun = True
+            trajectory.mark_filled(K)
         return actions, rewards, dones
 
     def observation(self) -> torch.Tensor:

@@ -70,6 +70,7 @@ class TrajectoryBuffer:
         self._state_views = [self._typed_states(c) for c in self._chunks] if self.has_states else None
         self._state_slots = ([[(v[0][t, :n], v[1][t, :n]) for t in range(T + 1)] for v in self._state_views]
                              if self.has_states else None)
+        self._begun = False            # states=True: row 0 of the first chunk has been set (begin / a fused rollout)
         self._pending = [None, None]   # outstanding collective per chunk
         self._gathered = [None, None]  # its output buffer
         self._cur = 0
@@ -176,7 +177,7 @@ class TrajectoryBuffer:
         policy sees at step t (row T: the bootstrap state)."""
         if not self.has_states:
             raise RuntimeError("this TrajectoryBuffer was built without states=True")
-        if not getattr(self, "_begun", False):
+        if not self._begun:
             raise RuntimeError("call begin(env) at the start of the first chunk: row 0 of the states is not set")
         if self.t < 1:
             raise RuntimeError("state_slot() follows next_slot() / store()")
@@ -184,11 +185,19 @@ class TrajectoryBuffer:
 
     def _carry_state(self, src_chunk: int, dst_chunk: int) -> None:
         """Row T of a finished chunk is row 0 of the next one."""
-        if self.has_states and getattr(self, "_begun", False):
+        if self.has_states and self._begun:
             (s_from, p_from), (s_to, p_to) = self._state_slots[src_chunk][self.T], self._state_slots[dst_chunk][0]
             if s_from.data_ptr() != s_to.data_ptr():
                 s_to.copy_(s_from)
                 p_to.copy_(p_from)
+
+    def mark_filled(self, num_steps: int) -> None:
+        """A kernel wrote ``num_steps`` whole slots of the current chunk (and, with ``states=True``, descriptor rows
+        0..num_steps) behind the buffer's back -- a fused rollout given ``trajectory=``."""
+        if not 0 <= num_steps <= self.T:
+            raise ValueError("num_steps out of range")
+        self.t = int(num_steps)
+        self._begun = True
 
     def states(self, env, t: int) -> torch.Tensor:
         """The (N, W, 5A) observation the policy saw at step t of the chunk being filled (t = len(self): the one the
