@@ -39,6 +39,12 @@ class GraphedRollout:
         s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             self.obs = env.reset()
+            if trajectory is not None and trajectory.has_states:
+                trajectory.clear()
+                trajectory.begin(env)  # row 0 of the very first chunk ...
+                # ... and a copy in row K: every iteration (the captured one included) starts by carrying row K over
+                trajectory.obs_src[self.K].copy_(trajectory.obs_src[0])
+                trajectory.obs_pos[self.K].copy_(trajectory.obs_pos[0])
             for _ in range(warmup):
                 self._iterate(record=False)
         torch.cuda.current_stream(dev).wait_stream(s)
@@ -51,14 +57,19 @@ class GraphedRollout:
     def _iterate(self, record: bool) -> None:
         env, traj = self.env, self.traj
         if traj is not None:
-            traj.clear()
+            if traj.has_states:  # unconditionally, so that the captured graph contains it whatever t was at capture time
+                traj._carry_state(traj._cur, traj._cur)
+            traj.t = 0
         obs = self.obs
         rews, dones = [], []
         for k in range(self.K):
             actions = self.policy(obs, k)
-            obs, rew, done, _ = env.step(actions)
-            if traj is not None:
-                traj.store(actions, rew, done)
+            if traj is None:
+                obs, rew, done, _ = env.step(actions)
+            else:  # agent.store's fields are written by the step kernel itself: no store launch in the graph
+                a_slot, r_slot, d_slot = traj.next_slot()
+                obs, rew, done, _ = env.step(actions, rewards_out=r_slot, dones_out=d_slot, actions_out=a_slot,
+                                             descriptors_out=traj.state_slot() if traj.has_states else None)
             rews.append(rew)
             dones.append(done)
         self.obs = obs

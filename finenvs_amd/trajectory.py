@@ -187,9 +187,8 @@ class TrajectoryBuffer:
         """Row T of a finished chunk is row 0 of the next one."""
         if self.has_states and self._begun:
             (s_from, p_from), (s_to, p_to) = self._state_slots[src_chunk][self.T], self._state_slots[dst_chunk][0]
-            if s_from.data_ptr() != s_to.data_ptr():
-                s_to.copy_(s_from)
-                p_to.copy_(p_from)
+            s_to.copy_(s_from)
+            p_to.copy_(p_from)
 
     def mark_filled(self, num_steps: int) -> None:
         """A kernel wrote ``num_steps`` whole slots of the current chunk (and, with ``states=True``, descriptor rows

@@ -158,3 +158,31 @@ def test_another_ranks_descriptors_render_on_this_rank(fe, fo):
     # bytes: what the states cost per env-step against the observations they stand for
     assert traj1._layout["obs_src"][1] + traj1._layout["obs_pos"][1] == (T + 1) * traj1.C * (8 + 8 * A)
     assert seen[1][0][0].numel() * 8 == 40 * W * A
+
+
+def test_graphed_rollout_keeps_states_as_descriptors(fe, fo):
+    """A hipGraph of K x (policy -> step) with a states=True trajectory: no store launch in the graph (the step kernel
+    writes actions, rewards, dones and descriptors into the slots), row 0 of every replay's chunk is the previous
+    replay's bootstrap row, and every stored state renders to the observation an eager loop sees at that step."""
+    from finenvs_amd.data import synthetic
+    from finenvs_amd.rollout import GraphedRollout
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    N, A, W, K = 300, 2, 6, 8
+    prices, day_id, _ = synthetic.synthetic_series(6, A, 40, 3, 0.05)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    g = torch.Generator().manual_seed(1)
+    ring = [(torch.rand((N, A), generator=g) * 2 - 1).float().cuda() for _ in range(K)]
+    mk = lambda: fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, redraw="device", seed=5, obs_buffers=2)
+    eager, graphed = mk(), mk()
+    traj = TrajectoryBuffer(K, N, A, states=True)
+    roll = GraphedRollout(graphed, lambda obs, k: ring[k], K, trajectory=traj, warmup=0)
+    obs_e = eager.reset().clone()
+    for rep in range(10):  # 80 steps: crosses day ends
+        roll.run()
+        for k in range(K):
+            assert torch.equal(traj.states(graphed, k), obs_e), f"replay {rep} state {k}"
+            obs_e, rew_e, done_e, _ = eager.step(ring[k])
+            obs_e = obs_e.clone()
+            assert torch.equal(traj.rewards[k], rew_e) and torch.equal(traj.dones[k], done_e) and torch.equal(traj.actions[k], ring[k])
+        assert torch.equal(traj.states(graphed, K), obs_e), f"replay {rep} bootstrap state"
