@@ -1,0 +1,409 @@
+// fe_device_common.h -- part of fe_env.hip (one translation unit; see the overview there): constants and build knobs, the kernel parameter block, Philox, the sleeve accounting (TSE:298-421, 447-475), LDS tile layout, input loads.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "finenvs_amd.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+// Single-asset kernels: 7 waves per SIMD = 72 VGPRs, the most they reach without scratch spills
+// (8 spills 12-36 B/lane and measured slower); the 20 KiB LDS stage allows 7 workgroups per CU too.
+// Multi-asset kernels carry the per-sleeve LDS arrays (26 KiB at 8 envs x 30 assets -> 6 per CU),
+// so they are built for 6 waves per SIMD (80 VGPRs, no spills).
+#ifndef FE_MIN_WAVES_PER_EU
+#define FE_MIN_WAVES_PER_EU 7
+#endif
+// Cache policy of the observation stores (raw buffer stores, aux bits: 1 = sc0, 2 = nt, 16 = sc1).
+// -2 (default) = chosen per kernel variant; in both cases the point is that a 0.17-150 GB store stream must not
+// evict what phase 1 and phase 2 re-read every step from the 4 MiB L2s:
+//   * single-asset envs: sc1 (write-through, the line is dropped from L2).  The per-env state, the action and
+//     the tables then stay L2-resident, which shortens the kernel's start-up chain (index load -> bar gather ->
+//     accounting -> first store): measured at 64k envs (tools/ab_step.py, interleaved in one process, three
+//     boxes) 34.8 -> 31.1, 34.5 -> 32.0, 34.8 -> 33.6 us per step; nt gains about 1 % less, sc0|sc1 the same.
+//   * multi-asset envs: nt.  Measured at 1M envs x 30 assets (round 1, profiles/r01_microbench/store_policy.txt): FETCH_SIZE
+//     6.9 GiB -> 0.4 GiB per launch and 26.4 -> 25.0 ms; sc1 gives the same fetch reduction but 25.6 ms.
+// -1 = plain everywhere; -3 = the round-1 choice (plain for single-asset, nt for multi-asset); >= 0 = that aux
+// everywhere (experiment builds).
+// "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their
+// -D set here and are only ever loaded by explicit path
+#ifndef FE_NO_DESC   /* experiment builds only: compile the step kernel's descriptor outputs out (A/B of their cost) */
+#define FE_NO_DESC 0
+#endif
+#ifndef FE_BUILD_TAG
+#define FE_BUILD_TAG ""
+#endif
+#ifndef FE_STORE_AUX
+#define FE_STORE_AUX -2
+#endif
+// Structure of the single-asset step kernel (experiments; tools/ab_step.py):
+//   0  software pipeline: per tile [account (wave 0) | barrier | stream (4 waves) | barrier], next tile's
+//      loads prefetched under the stream
+//   1  up-front accounting: wave w accounts the workgroup's w-th tile, all four at once; one barrier; then the
+//      workgroup streams its tiles back to back with no further barriers
+//   2  the north star's literal "one wavefront per env": lane 0 of a wavefront accounts one env, then the
+//      wavefront streams that env's observation; no workgroup barriers at all (measured A/B for DESIGN.md)
+#ifndef FE_STEP_VARIANT
+#define FE_STEP_VARIANT 0
+#endif
+// Timing-only ablations of the step kernel (WRONG outputs; experiment builds only -- tools/ab_step.py):
+//   bit 0  no phase 1: descriptors fabricated from the env number, no state / bar loads, no write-back
+//   bit 1  no table loads in phase 2 (the image is built from constants)
+//   bit 2  no LDS transpose in phase 2 (registers stored directly)
+//   bit 3  phase 1 without its global stores (state write-back, reward, done)
+//   bit 4  phase 1 without its global loads (constants instead)
+//   bit 5  phase 1 without the accounting arithmetic
+//   (bits 6 / 7 -- phase 1 skipped on the first tile only / on all but the first -- were used once and removed)
+#ifndef FE_ABLATE
+#define FE_ABLATE 0
+#endif
+// Diagnostic build: every workgroup of the single-asset step kernel writes four s_memrealtime stamps (100 MHz)
+// -- start, first tile accounted, first tile streamed, end -- into the buffer bound as fe_env_bind_stats'
+// eval_return argument (grid * 8 u64; the statistics themselves are off in this build).  tools/stamp_step.py.
+#ifndef FE_STAMP
+#define FE_STAMP 0
+#endif
+// 1 (default): the single-asset f64 step kernel issues the first tile's table loads before its accounting
+// (0 = A/B arm).  Measured on a shared ring (profiles/r02_microbench/ab_hoist.txt): 30.57 -> 29.32 us at config 2.
+// Not for f32 observations: they run 6 workgroups per CU (80 VGPRs) and the 16 extra live registers spill.
+#ifndef FE_HOIST_FIRST
+#define FE_HOIST_FIRST 1
+#endif
+#ifndef FE_F32_WAVES
+#define FE_F32_WAVES 6
+#endif
+template <typename OT>
+constexpr bool kHoistFirst = FE_HOIST_FIRST != 0 && (sizeof(OT) == 8 || FE_F32_WAVES <= 5);
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+int hip_fail(hipError_t e, const char *what) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return FE_ERR_HIP;
+}
+
+// Exact unsigned 32-bit division by a launch-time constant (Granlund & Montgomery 1994).
+struct FastDiv {
+    uint32_t m, sh1, sh2, d;
+};
+
+FastDiv make_fastdiv(uint32_t d) {
+    FastDiv f;
+    f.d = d;
+    uint32_t l = 0;
+    while ((1ull << l) < d) ++l;  // ceil(log2 d)
+    f.m = (uint32_t)(((1ull << 32) * ((1ull << l) - d)) / d + 1);
+    f.sh1 = l < 1 ? l : 1;
+    f.sh2 = l > 1 ? l - 1 : 0;
+    return f;
+}
+
+__device__ __forceinline__ uint32_t fdiv(uint32_t n, const FastDiv &f) {
+    uint32_t t = __umulhi(f.m, n);
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+struct Params {
+    const double *P;
+    const double *LR;
+    const float *LR32;  // optional f32 copy of LR for f32 observations (fe_env_bind_f32_table)
+    int64_t *env_idx;
+    int64_t *spot0;
+    float *cash;
+    float *lng;
+    float *sht;
+    double *margin;
+    uint8_t *terminated;
+    float *ep_ret;
+    unsigned long long *counters;
+    float *run_ret;      // optional episode statistics (fe_env_bind_stats): running return per env
+    double *stat_acc;    // [0] finished training episodes, [1] sum of their returns, [2] sum of squares
+    float *stat_eval;    // [0] return of the eval env's last finished episode, [1] how many it finished
+    const float *actions;
+    void *obs;
+    double *rew;
+    int32_t *done;
+    int64_t *desc_src;   // optional (fe_env_step_traj): descriptors of the observation this step returns
+    double *desc_pos;
+    float *act_store;    // optional (fe_env_step_traj): the actions, copied into a trajectory slot
+    int64_t N, D, L;
+    int64_t num_tiles;
+    int64_t eval_env;
+    uint64_t seed;
+    int32_t W, A, EB;
+    int32_t evaluate, redraw_mode;
+    uint32_t env_elems;  // W * 5 * A, observation elements per env
+    FastDiv div_WA;  // by tuples per env (W * A)
+    FastDiv div_A;
+    float scale32, ms32, c32, imr32, S32;
+    double comm, imr, one_mmr, S;
+};
+
+// ---- Philox4x32-10, the redraw generator of redraw_mode 1 ----
+__device__ __forceinline__ uint32_t philox_u32(uint64_t seed, uint64_t counter) {
+    uint32_t c0 = (uint32_t)counter, c1 = (uint32_t)(counter >> 32), c2 = 0x46454e56u, c3 = 0u;
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    return c0;
+}
+
+// max(x, 0) that lets a NaN through, as torch.relu does
+__device__ __forceinline__ float relu32(float x) { return x > 0.0f ? x : (x != x ? x : 0.0f); }
+__device__ __forceinline__ double relu64(double x) { return x > 0.0 ? x : (x != x ? x : 0.0); }
+
+// Workgroup barrier that orders LDS traffic only.  Everything the waves of a workgroup hand to each other inside
+// these kernels goes through LDS (descriptors, sleeve rewards / flags, actions); their global stores are
+// fire-and-forget and nothing in the same launch reads them back.  __syncthreads() would also wait for every
+// outstanding global store of the wave (s_waitcnt vmcnt(0)): in the step kernel that drains the observation
+// store stream at every tile boundary and puts a store acknowledgement on the start-up chain.
+__device__ __forceinline__ void lds_barrier() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
+}
+// the step kernel's barriers (FE_SYNC=1: the round-1 form, for A/B)
+#ifndef FE_SYNC
+#define FE_SYNC 0
+#endif
+__device__ __forceinline__ void tile_barrier() {
+#if FE_SYNC
+    __syncthreads();
+#else
+    lds_barrier();
+#endif
+}
+
+struct Sleeve {
+    float cash, lng, sht;
+    double margin;
+    double pos_obs;
+    double rew;
+    bool bankrupt;
+};
+
+// One (env, asset) account for one bar: TSE:298-421 (trade), TSE:428-431
+// (position feature), TSE:447-475 (reward).  Pure register arithmetic.
+__device__ __forceinline__ void sleeve_step(const Params &p, float action, double O, double H, double Lo,
+                                            double C, Sleeve &s) {
+    float cash = s.cash, lng = s.lng, sht = s.sht;
+    double margin = s.margin;
+    float comm = 0.0f;  // TSE:305
+
+    // TSE:298-302  round-half-even then clamp
+    float sc = rintf(action * p.scale32);
+    sc = sc < -p.ms32 ? -p.ms32 : sc;
+    sc = sc > p.ms32 ? p.ms32 : sc;
+    float pos = sc < 0.0f ? 0.0f : sc;  // TSE:344-351
+    float neg = sc > 0.0f ? 0.0f : sc;
+
+    // sell long positions first, TSE:353-361
+    float nl = relu32(lng + neg);
+    float sell = lng - nl;
+    neg += sell;
+    comm += sell * p.c32;
+    cash = (float)((double)cash + (double)sell * (O - p.comm));
+    lng = nl;
+
+    // buy back shorts and re-mark the margin account, TSE:367-383
+    float ns = relu32(sht - pos);
+    float bb = sht - ns;
+    pos -= bb;
+    comm += bb * p.c32;
+    cash = (float)((double)cash - (double)bb * (O + p.comm));
+    sht = ns;
+    double nm = (double)(p.imr32 * sht) * O;
+    cash = (float)((double)cash - (nm - margin));
+    margin = nm;
+
+    // long entry unless unaffordable, TSE:385-399
+    if ((double)cash - (double)pos * (O + p.comm) < 0.0) pos = 0.0f;
+    comm += pos * p.c32;
+    cash = (float)((double)cash - (double)pos * (O + p.comm));
+    lng += pos;
+
+    // short entry unless the 150% margin is unaffordable, TSE:401-421
+    float q = -neg;
+    if (((double)cash - p.imr * ((double)q * O)) - (double)(q * p.c32) < 0.0) {
+        neg = 0.0f;
+        q = -neg;
+    }
+    comm += q * p.c32;
+    double req = p.imr * ((double)q * O);
+    cash = (float)((double)cash - (req + (double)(q * p.c32)));
+    margin += req;
+    sht += q;
+
+    // observation feature, rendered post-trade / pre-margin-check, TSE:428-431
+    s.pos_obs = (double)(lng - sht) * C / p.S;
+
+    // reward, TSE:447-475
+    bool done = cash < 0.0f;
+    double rew;
+    {
+        double call = relu64((double)sht * H * p.one_mmr - margin);
+        cash = (float)((double)cash - call);
+        margin += call;
+        done |= cash < 0.0f;
+        rew = -call;
+    }
+    {
+        double rel = relu64(margin - (double)sht * Lo * p.imr);
+        margin -= rel;
+        cash = (float)((double)cash + rel);
+    }
+    {
+        double call = relu64((double)sht * C * p.one_mmr - margin);
+        cash = (float)((double)cash - call);
+        margin += call;
+        done |= cash < 0.0f;
+        rew += -call;
+    }
+    if (done) {
+        lng = 0.0f;
+        sht = 0.0f;
+    }
+    rew += (double)(lng - sht) * (C - O);
+    rew -= (double)comm;
+
+    s.cash = cash; s.lng = lng; s.sht = sht; s.margin = margin;
+    s.rew = rew;
+    s.bankrupt = done;
+}
+
+template <typename OT, int VEC>
+struct alignas(sizeof(OT) * VEC) Pack {
+    OT v[VEC];
+};
+
+// Tuples one wavefront turns per phase-2 iteration: 5120 bytes of observation = five full
+// 1-KiB store instructions (128 f64 tuples of 40 B, or 256 f32 tuples of 20 B).
+constexpr int kStageBytes = 5120;
+
+// LDS carve-up for a tile of EB envs x A assets (S = EB*A sleeves):
+//   stage[4][5120 B] wave-private 5-tuple images (phase 2)
+//   int64 src[EB]  element offset of the window's first row in the LR table
+//   double pos[S]  position feature per sleeve
+//   double rew[S]  sleeve reward before the liquidation fee   (A > 1 only)
+//   float  shr[S]  long+short after the reward step            (A > 1 only)
+//   int    flg[S]  sleeve done flag                            (A > 1 only)
+//   int    any[EB] env-level done                              (A > 1 only)
+__host__ __device__ inline size_t lds_bytes(int EB, int A) {
+    size_t S = (size_t)EB * A;
+    size_t b = 4 * (size_t)kStageBytes + (size_t)EB * 8 + S * 8;
+    if (A > 1) b += S * 8 + S * 4 + S * 4 + (size_t)EB * 4;
+#if FE_STEP_VARIANT == 1
+    if (A == 1) b = 4 * (size_t)kStageBytes + 4 * ((size_t)EB * 16);  // descriptors of four tiles at once
+#elif FE_STEP_VARIANT == 2
+    if (A == 1 && b < 4 * (size_t)kStageBytes + 64) b = 4 * (size_t)kStageBytes + 64;  // one descriptor slot per wavefront
+#endif
+    return (b + 15) & ~(size_t)15;
+}
+
+struct TileLds {
+    int64_t *src;  // [EB]  element offset of the observation window's first row in the LR table
+    double *pos;   // [S]   position feature per sleeve
+    double *rew;   // [S]   sleeve reward before the liquidation fee   (A > 1 only)
+    float *shr;    // [S]   long+short after the reward step            (A > 1 only)
+    int *flg;      // [S]   sleeve done flag                            (A > 1 only)
+    int *any;      // [EB]  env-level done                              (A > 1 only)
+};
+
+__device__ __forceinline__ TileLds carve_lds(unsigned char *base, int EB, int S) {
+    TileLds l;
+    l.src = reinterpret_cast<int64_t *>(base);
+    l.pos = reinterpret_cast<double *>(l.src + EB);
+    l.rew = l.pos + S;
+    l.shr = reinterpret_cast<float *>(l.rew + S);
+    l.flg = reinterpret_cast<int *>(l.shr + S);
+    l.any = l.flg + S;
+    return l;
+}
+
+// What phase 1 reads for one sleeve.  Loading is split in two dependent stages so that the step
+// kernel can prefetch them for the NEXT tile while the current tile's observation streams out:
+//   head: env_idx, spot0 (coalesced)          body: state + the bar/probe gathers that need the head
+struct SleeveIn {
+    int64_t idx, s0, nxt;
+    double4 bar;
+    double probe, margin;
+    float cash, lng, sht;
+};
+
+__device__ __forceinline__ void load_head(const Params &p, bool active, int64_t n, int64_t &idx, int64_t &spot) {
+    idx = 0;
+    spot = 0;
+#if FE_ABLATE & 16
+    idx = n % p.D;
+    spot = 1;
+    return;
+#endif
+    if (active) {
+        idx = p.env_idx[n];
+        spot = p.spot0[n];
+    }
+}
+
+// the part of the body that needs no index: account state of the sleeve (issued together with the head for a
+// workgroup's first tile, so that only the L2-resident bar gather sits behind the index load)
+__device__ __forceinline__ void load_state(const Params &p, bool active, int64_t sl, SleeveIn &in) {
+    if (!active) return;
+#if FE_ABLATE & 16
+    in.cash = 1e4f; in.lng = (float)(sl & 3); in.sht = 0.0f; in.margin = 0.0;
+    return;
+#endif
+    in.cash = p.cash[sl];
+    in.lng = p.lng[sl];
+    in.sht = p.sht[sl];
+    in.margin = p.margin[sl];
+}
+
+// the part that does: the bar at the window's last row and the NaN probe of the next row
+__device__ __forceinline__ void load_bar(const Params &p, int A, int a, bool active, int64_t idx, int64_t spot,
+                                         SleeveIn &in) {
+    if (!active) return;
+#if FE_ABLATE & 16
+    in.idx = idx; in.s0 = spot + 1; in.nxt = spot + p.W + 1; in.bar = make_double4(100.0, 101.0, 99.0, 100.5);
+    in.probe = 0.0;
+    return;
+#endif
+    const int64_t rs = 4 * (int64_t)A;
+    const int64_t L = p.L;
+    in.idx = idx;
+    in.s0 = spot + 1;  // TSE:281-282
+    int64_t last = in.s0 + p.W - 1;
+    last = last < L ? last : L - 1;  // memory safety only; the done logic keeps last < L
+    in.nxt = last + 1;               // TSE:480
+    in.bar = *reinterpret_cast<const double4 *>(p.P + (idx * L + last) * rs + 4 * a);
+    in.probe = 0.0;
+    if (in.nxt < L) in.probe = p.LR[(idx * L + in.nxt) * rs + 4 * a];
+}
+
+__device__ __forceinline__ void load_body(const Params &p, int A, int a, bool active, int64_t sl, int64_t idx,
+                                          int64_t spot, SleeveIn &in) {
+    load_bar(p, A, a, active, idx, spot, in);
+    load_state(p, active, sl, in);
+}
+
+}  // namespace

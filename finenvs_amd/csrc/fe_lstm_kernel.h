@@ -1,0 +1,348 @@
+// fe_lstm_kernel.h -- part of fe_env.hip (one translation unit; see the overview there): K-step fused rollout with the reference's LSTM actor on MFMA, and its exact-operation sigmoid / tanh.
+#pragma once
+#include "fe_device_common.h"
+#include "fe_rollout_kernels.h"
+
+namespace {
+
+// ---- f2, LSTM head: the actor of the reference's own time-series scripts, on the matrix cores ----
+// finenvs/agents/networks/lstm.py:28-57 -- nn.LSTM(5, H, batch_first) from a zero state over the W rows of the
+// observation, Linear(H, 1) on the last hidden state, Tanh (continuous_actor.py:104-126) -- evaluated on
+// states.float() per (env, asset) pair; examples/time_series/PPO_LSTM_testing_SPY.py:43-52 is the loop this fuses.
+// Per time step the gates are a (4H) x (H + 8) x (pairs) contraction, G^T = [Whh | Wx] . [h_{t-1} ; x_t]^T:
+//   * gate rows on the M side of v_mfma_f32_32x32x2_f32, 32 (env, asset) pairs on the N side; the rows are packed by
+//     the host so that an accumulator lane holds all four gates of four hidden units of ITS pair (row
+//     R = 32 mt + 8 b + 4 half + gate <-> unit 8 mt + 4 half + b): the cell update is in-lane, c_t never leaves
+//     the registers, and h_t goes to LDS as one 16-byte store per lane -- already in the [pair][unit] layout the next
+//     step's B operand reads with one ds_read_b128 per four MFMAs;
+//   * the recurrent weights stay in REGISTERS for the whole launch: Whh for H = 128 is 256 KiB, more than the LDS,
+//     but split over the 8 wavefronts of a 512-thread workgroup it is 128 VGPRs per lane (2 wavefronts per SIMD,
+//     256 VGPRs each); every wavefront owns MPW row tiles and runs all the workgroup's 32-pair column tiles;
+//   * the input part (K = 8: four log-returns | position, 1 for the bias, 0, 0) is four more MFMAs per tile;
+//   * the f32 MFMA is an fmaf chain in k order, and sigmoid / tanh are built from rintf, fmaf, ldexpf and IEEE
+//     division only (lstm_exp_nonpos), so the test-side CPU restatement (fo_policy_lstm) reproduces every
+//     action BIT FOR BIT; against torch's own nn.LSTM the actions agree to ~1e-7.
+// One barrier per time step (h double-buffered in LDS); the last hidden state is reduced by the pair's accounting lane.
+constexpr int kLstmBlock = 512;
+
+struct LstmArgs {
+    const float *lr32;  // (D, L, 4A) f32 copy of the log-return table
+    const float *whh;   // (4H, H) f32, packed row order
+    const float *wx;    // (4H, 8) f32, packed row order: w_ih[0..3], w_ih[4], b_ih + b_hh, 0, 0
+    const float *wout;  // (H)
+    float bout;
+    int32_t H, out_act, K;  // out_act: 0 tanh (the reference's actor), 1 clamp to [-1, 1]
+    int64_t *obs_src;
+    double *obs_pos;
+    float *actions_out;
+    double *rew_out;
+    int32_t *done_out;
+    // training rollouts (PPO_agent.py:98-108): actions = clamp(mean + std * noise, -1, 1), the eval env acts on the mean
+    const float *noise;  // (K, N*A) standard normal draws, or null: act on the mean
+    float std;
+    float *means_out;    // (K, N*A) or null
+    int64_t *traj_src;   // (K + 1, N) or null: descriptors of the state the policy sees at every step (+ the last one)
+    double *traj_pos;    // (K + 1, N*A)
+};
+
+template <int NT> struct LstmGeom {
+    static constexpr int H = 32 * NT;
+    static constexpr int MT = H / 8;                        // 32-row gate tiles
+    static constexpr int MPW = MT >= 8 ? MT / 8 : 1;        // row tiles per wavefront
+    static constexpr int NSPLIT = MT >= 8 ? 1 : 8 / MT;     // wavefronts sharing a row tile split the column tiles
+    static constexpr int SP = NT == 4 ? 64 : 128;           // (env, asset) pairs per workgroup tile
+    static constexpr int MAXNT = SP / 32 / NSPLIT;          // column tiles per wavefront
+    static constexpr int HP = H + 4;                        // LDS row length of h: 16 bytes against bank conflicts
+};
+
+__host__ __device__ inline size_t lstm_lds_bytes(int EB, int A, int H, int SP) {
+    size_t S = (size_t)EB * A;
+    size_t b = (size_t)EB * 8 + S * 8 + S * 8 + S * 4 + S * 4 + (size_t)EB * 4;  // TileLds
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)EB * 8;  // redrawn day per env
+    b = (b + 15) & ~(size_t)15;
+    b += 2 * (size_t)SP * (H + 4) * 4;  // h, double-buffered
+    b += (size_t)H * 4;                 // wout
+    return (b + 15) & ~(size_t)15;
+}
+
+// ---- the LSTM head's sigmoid / tanh: exactly-rounded operations only, two activations per instruction ----
+//   e = exp(-s |x|) (s = 1 sigmoid, 2 tanh; argument clamped at -60), Cephes expf's reduction and polynomial;
+//   sigmoid = (x >= 0 ? 1 : e) / (1 + e),   tanh = copysign((1 - e) / (1 + e), x).
+// Every step is an IEEE-exact f32 operation (mul, fma, rint, ldexp, and a division), so the same sequence on the CPU
+// (fo_lstm_sigmoid / fo_lstm_tanh of the tests' restatement) gives the same bits.  The f32 MFMA shares the vector
+// ALUs with these (SQ_VALU_MFMA_COEXEC_CYCLES = 0), so their instruction count is kernel time: the chains run on
+// pairs of activations with packed-f32 instructions (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), and the division
+// is the correctly-rounded rcp + fma sequence the compiler itself emits for `/`, minus its v_div_scale / v_div_fixup
+// range handling -- the denominator is in [1, 2] and the numerator in {0} U [2^-87, 1], where that handling is the
+// identity (this is why the argument clamp is -60: a smaller numerator would need the scaling).
+// NaN is not propagated (a NaN pre-activation acts like -60); the host refuses non-finite weights.
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ v2f pk_fma(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f pk_splat(float v) { return (v2f){v, v}; }
+
+__device__ __forceinline__ v2f lstm_exp_nonpos2(v2f y0) {
+    v2f y = {fmaxf(y0.x, -60.0f), fmaxf(y0.y, -60.0f)};
+    v2f n = y * pk_splat(1.44269504f);
+    n = (v2f){rintf(n.x), rintf(n.y)};
+    v2f r = pk_fma(n, pk_splat(-0.693359375f), y);
+    r = pk_fma(n, pk_splat(2.12194440e-4f), r);
+    v2f q = pk_splat(1.9875691500e-4f);
+    q = pk_fma(q, r, pk_splat(1.3981999507e-3f));
+    q = pk_fma(q, r, pk_splat(8.3334519073e-3f));
+    q = pk_fma(q, r, pk_splat(4.1665795894e-2f));
+    q = pk_fma(q, r, pk_splat(1.6666665459e-1f));
+    q = pk_fma(q, r, pk_splat(5.0000001201e-1f));
+    const v2f r2 = r * r;
+    q = pk_fma(q, r2, r);
+    q = q + pk_splat(1.0f);
+    return (v2f){ldexpf(q.x, (int)n.x), ldexpf(q.y, (int)n.y)};
+}
+
+// num / den, correctly rounded, for den in [1, 2] and num in {0} U [2^-87, 1] (see above)
+__device__ __forceinline__ v2f lstm_div2(v2f num, v2f den) {
+    v2f r = {__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+    const v2f e0 = pk_fma(-den, r, pk_splat(1.0f));
+    r = pk_fma(e0, r, r);
+    v2f q = num * r;
+    v2f rem = pk_fma(-den, q, num);
+    q = pk_fma(rem, r, q);
+    rem = pk_fma(-den, q, num);
+    return pk_fma(rem, r, q);
+}
+
+// two activations at once; T0 / T1: the element is a tanh (else a sigmoid)
+template <bool T0, bool T1>
+__device__ __forceinline__ v2f lstm_act2(v2f x) {
+    const v2f ax = {fabsf(x.x), fabsf(x.y)};
+    const v2f e = lstm_exp_nonpos2(ax * (v2f){T0 ? -2.0f : -1.0f, T1 ? -2.0f : -1.0f});
+    const v2f den = pk_splat(1.0f) + e;
+    v2f num;
+    num.x = T0 ? 1.0f - e.x : (x.x >= 0.0f ? 1.0f : e.x);
+    num.y = T1 ? 1.0f - e.y : (x.y >= 0.0f ? 1.0f : e.y);
+    v2f v = lstm_div2(num, den);
+    if (T0) v.x = copysignf(v.x, x.x);
+    if (T1) v.y = copysignf(v.y, x.y);
+    return v;
+}
+
+__device__ __forceinline__ float lstm_tanh(float x) { return lstm_act2<true, true>((v2f){x, x}).x; }
+
+__global__ __launch_bounds__(kBlock) void fe_lstm_activations_kernel(const float *x, float *sig, float *tnh, int64_t n) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < n; i += (int64_t)gridDim.x * kBlock) {
+        const v2f v = lstm_act2<false, true>((v2f){x[i], x[i]});
+        sig[i] = v.x;
+        tnh[i] = v.y;
+    }
+}
+
+template <bool SINGLE, int NT>
+__global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm_kernel(const Params p, const LstmArgs r) {
+    using G = LstmGeom<NT>;
+    constexpr int H = G::H, HP = G::HP, MPW = G::MPW, NSPLIT = G::NSPLIT, MAXNT = G::MAXNT, NG = H / 8;
+    constexpr int JB = MPW == 1 ? 2 : 1;  // column tiles processed together
+    static_assert(MAXNT % JB == 0, "column tiles per wavefront must come in whole groups");
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const int S = EB * A;
+    const int W = p.W;
+    const TileLds l = carve_lds(smem, EB, S);
+    size_t off = (size_t)EB * 8 + (size_t)S * 8 + (size_t)S * 8 + (size_t)S * 4 + (size_t)S * 4 + (size_t)EB * 4;
+    off = (off + 7) & ~(size_t)7;
+    int64_t *l_idx = reinterpret_cast<int64_t *>(smem + off);
+    off = (off + (size_t)EB * 8 + 15) & ~(size_t)15;
+    float *s_h = reinterpret_cast<float *>(smem + off);  // [2][SP][HP]
+    float *s_wout = s_h + 2 * (size_t)G::SP * HP;
+    const int tid = threadIdx.x;
+    const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
+    const int a = SINGLE ? 0 : tid - e * A;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t NA = p.N * A;
+    const int64_t rstride = 4 * (int64_t)A;
+    const int mt0 = NSPLIT == 1 ? wave * MPW : wave % G::MT;  // first gate-row tile of this wavefront
+    const int nsub = NSPLIT == 1 ? 0 : wave / G::MT;          // its share of the column tiles
+
+    // this wavefront's slice of the weights: A fragments, lane (row = lane & 31, k half = lane >> 5)
+    float4 whh[MPW][NG], wx[MPW];
+#pragma unroll
+    for (int i = 0; i < MPW; ++i) {
+        const size_t R = (size_t)32 * (mt0 + i) + col;
+        wx[i] = *reinterpret_cast<const float4 *>(r.wx + R * 8 + 4 * half);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) whh[i][g] = *reinterpret_cast<const float4 *>(r.whh + R * H + 8 * g + 4 * half);
+    }
+    for (int i = tid; i < H; i += kLstmBlock) s_wout[i] = r.wout[i];
+
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        const bool active = e < ebt;
+        const int64_t n = n0 + e;
+        const int64_t sl = n * A + a;
+        SleeveReg st;
+        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
+        st.obs_row = 0; st.obs_pos = 0.0;
+        if (active) {
+            st.idx = p.env_idx[n];
+            st.spot = p.spot0[n];
+            st.cash = p.cash[sl];
+            st.lng = p.lng[sl];
+            st.sht = p.sht[sl];
+            st.margin = p.margin[sl];
+            const double pos0 = r.obs_pos[sl];
+            l.pos[e * A + a] = pos0;
+            if (a == 0) l.src[e] = r.obs_src[n];
+            if (r.traj_src) {  // row 0: the state the first policy evaluation sees
+                r.traj_pos[sl] = pos0;
+                if (a == 0) r.traj_src[n] = r.obs_src[n];
+            }
+        }
+        __syncthreads();  // also covers s_wout on the first tile
+        const int pairs = ebt * A;
+        const int ntiles = (pairs + 31) / 32;
+        for (int k = 0; k < r.K; ++k) {
+            // ---- policy: W recurrent steps, every wavefront its gate rows for all of its column tiles ----
+            const float *xsrc[MAXNT];
+            float4 xh[MAXNT], xc[MAXNT];
+            float cst[MPW][MAXNT][4];
+#pragma unroll
+            for (int j = 0; j < MAXNT; ++j) {
+                const int q = (nsub + j * NSPLIT) * 32 + col;
+                const int qc = q < pairs ? q : pairs - 1;
+                const int ee = SINGLE ? qc : (int)fdiv((uint32_t)qc, p.div_A);
+                const int aa = SINGLE ? 0 : qc - ee * A;
+                xsrc[j] = r.lr32 + l.src[ee] + 4 * aa;
+                xh[j] = make_float4((float)l.pos[qc], 1.0f, 0.0f, 0.0f);
+                xc[j] = half == 0 ? *reinterpret_cast<const float4 *>(xsrc[j]) : xh[j];
+#pragma unroll
+                for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) cst[i][j][b] = 0.0f;
+            }
+            for (int t = 0; t < W; ++t) {
+                const float *hprev = s_h + (size_t)((t + 1) & 1) * G::SP * HP;
+                float *hnext = s_h + (size_t)(t & 1) * G::SP * HP;
+                float4 xn[MAXNT];
+                const int tn = t + 1 < W ? t + 1 : t;  // the next step's rows, one step ahead of their use
+#pragma unroll
+                for (int j = 0; j < MAXNT; ++j)
+                    xn[j] = half == 0 ? *reinterpret_cast<const float4 *>(xsrc[j] + (int64_t)tn * rstride) : xh[j];
+                // JB column tiles at a time: with MPW row tiles that is MPW * JB >= 2 independent accumulator chains,
+                // so a dependent MFMA never waits for its predecessor's 16 passes
+#pragma unroll
+                for (int j0 = 0; j0 < MAXNT; j0 += JB) {
+                    if (nsub + j0 * NSPLIT < ntiles) {  // (a trailing tile of the group past `pairs` computes on clamped rows)
+                        f32x16 acc[MPW][JB];
+#pragma unroll
+                        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < JB; ++jj)
+#pragma unroll
+                                for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = 0.0f;
+#pragma unroll
+                        for (int m = 0; m < 4; ++m)
+#pragma unroll
+                            for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                                for (int jj = 0; jj < JB; ++jj) {
+                                    const float4 xv = xc[j0 + jj];
+                                    const float xs = m == 0 ? xv.x : (m == 1 ? xv.y : (m == 2 ? xv.z : xv.w));
+                                    const float ws = m == 0 ? wx[i].x : (m == 1 ? wx[i].y : (m == 2 ? wx[i].z : wx[i].w));
+                                    acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, acc[i][jj], 0, 0, 0);
+                                }
+                        if (t > 0) {
+#pragma unroll
+                            for (int g = 0; g < NG; ++g) {
+                                float4 hb[JB];
+#pragma unroll
+                                for (int jj = 0; jj < JB; ++jj)
+                                    hb[jj] = *reinterpret_cast<const float4 *>(
+                                        hprev + (size_t)(32 * (nsub + (j0 + jj) * NSPLIT) + col) * HP + 4 * half + 8 * g);
+#pragma unroll
+                                for (int m = 0; m < 4; ++m)
+#pragma unroll
+                                    for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                                        for (int jj = 0; jj < JB; ++jj) {
+                                            const float4 wv = whh[i][g];
+                                            const float ws = m == 0 ? wv.x : (m == 1 ? wv.y : (m == 2 ? wv.z : wv.w));
+                                            const float hs = m == 0 ? hb[jj].x : (m == 1 ? hb[jj].y : (m == 2 ? hb[jj].z : hb[jj].w));
+                                            acc[i][jj] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, hs, acc[i][jj], 0, 0, 0);
+                                        }
+                            }
+                        }
+                        // cell update, in-lane: acc[i][jj][4b + gate] belongs to unit 8 (mt0 + i) + 4 half + b
+#pragma unroll
+                        for (int i = 0; i < MPW; ++i)
+#pragma unroll
+                            for (int jj = 0; jj < JB; ++jj) {
+                                const int j = j0 + jj;
+                                float hv[4], og[4];
+#pragma unroll
+                                for (int b = 0; b < 4; ++b) {
+                                    const v2f sif = lstm_act2<false, false>((v2f){acc[i][jj][4 * b + 0], acc[i][jj][4 * b + 1]});
+                                    const v2f tgo = lstm_act2<true, false>((v2f){acc[i][jj][4 * b + 2], acc[i][jj][4 * b + 3]});
+                                    const float t1 = sif.y * cst[i][j][b];
+                                    const float t2 = sif.x * tgo.x;
+                                    cst[i][j][b] = t1 + t2;
+                                    og[b] = tgo.y;
+                                }
+#pragma unroll
+                                for (int b = 0; b < 4; b += 2) {
+                                    const v2f tc = lstm_act2<true, true>((v2f){cst[i][j][b], cst[i][j][b + 1]});
+                                    hv[b] = og[b] * tc.x;
+                                    hv[b + 1] = og[b + 1] * tc.y;
+                                }
+                                *reinterpret_cast<float4 *>(hnext + (size_t)(32 * (nsub + j * NSPLIT) + col) * HP + 8 * (mt0 + i) + 4 * half) =
+                                    make_float4(hv[0], hv[1], hv[2], hv[3]);
+                            }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MAXNT; ++j) xc[j] = xn[j];
+                lds_barrier();  // h_t is complete
+            }
+            // ---- output layer: the pair's accounting lane reduces its last hidden state ----
+            float act = 0.0f;
+            if (active) {
+                const float *hl = s_h + (size_t)((W - 1) & 1) * G::SP * HP + (size_t)(e * A + a) * HP;
+                float o = r.bout;
+#pragma unroll 8
+                for (int u = 0; u < H; ++u) o = fmaf(s_wout[u], hl[u], o);
+                act = r.out_act == 0 ? lstm_tanh(o) : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o));
+                if (r.means_out) r.means_out[(int64_t)k * NA + sl] = act;
+                if (r.noise && n != p.eval_env) {  // distribution.sample() clamped; the eval env keeps the mean
+                    const float dev = r.std * r.noise[(int64_t)k * NA + sl];
+                    const float smp = act + dev;
+                    act = smp < -1.0f ? -1.0f : (smp > 1.0f ? 1.0f : smp);
+                }
+                if (r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
+            }
+            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
+                                 r.done_out + (int64_t)k * p.N);
+            if (active && r.traj_src) {  // row k + 1: the observation this step returns (own LDS entries: no barrier needed)
+                r.traj_pos[(int64_t)(k + 1) * NA + sl] = l.pos[e * A + a];
+                if (a == 0) r.traj_src[(int64_t)(k + 1) * p.N + n] = l.src[e];
+            }
+            lds_barrier();  // the new observation's descriptors are complete; everyone is done with h_W
+        }
+        if (active) {  // state and descriptors go back to HBM once per launch
+            p.cash[sl] = st.cash;
+            p.lng[sl] = st.lng;
+            p.sht[sl] = st.sht;
+            p.margin[sl] = st.margin;
+            r.obs_pos[sl] = l.pos[e * A + a];
+            if (a == 0) {
+                p.env_idx[n] = st.idx;
+                p.spot0[n] = st.spot;
+                r.obs_src[n] = l.src[e];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
