@@ -104,6 +104,7 @@ def test_lstm_activations_equal_oracle_bit_for_bit(fe, fo):
     (40, 30, 5, 128, 5, 40, 0.0, False),      # 30 sleeves, 2 envs per 64-pair tile
     (131, 5, 1, 64, 6, 45, 0.1, False),       # W = 1: no recurrent step at all
     (260, 1, 16, 32, 5, 50, 0.0, False),      # partial last tile (260 = 2 x 128 + 4)
+    (40, 1, 390, 32, 18, 30, 0.0, False),     # the reference's default window num_intervals=390 (TSE:19): 390 recurrent steps
 ])
 def test_lstm_rollout_equals_oracle_loop_bit_for_bit(fe, fo, N, A, W, H, days, bars, drop, evaluate):
     from finenvs_amd.rollout import FusedLSTMRollout
