@@ -30,6 +30,9 @@ constexpr int kBlock = 256;
 // everywhere (experiment builds).
 // "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their
 // -D set here and are only ever loaded by explicit path
+#ifndef FE_XCD_BLOCKED   /* experiment builds only: XCD-blocked tile order in the step / reset kernels */
+#define FE_XCD_BLOCKED 0
+#endif
 #ifndef FE_NO_DESC   /* experiment builds only: compile the step kernel's descriptor outputs out (A/B of their cost) */
 #define FE_NO_DESC 0
 #endif

@@ -304,6 +304,22 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
     }
 }
 
+// The k-th tile of this workgroup, or p.num_tiles when it has none left.  Default: grid-strided (tile t -> workgroup
+// t % grid, so t % 8 -- the XCD -- is stable per workgroup).  FE_XCD_BLOCKED (experiment builds): every XCD owns one
+// contiguous eighth of the tiles (tools/placement_modes.hip: plain stores gain 2 - 4 % at 20 GB from that mapping).
+__device__ __forceinline__ int64_t tile_at(const Params &p, int64_t k) {
+#if FE_XCD_BLOCKED
+    const int64_t G = gridDim.x;
+    if ((G & 7) == 0) {
+        const int64_t x = blockIdx.x & 7, j = blockIdx.x >> 3, gx = G >> 3, per = (p.num_tiles + 7) >> 3;
+        const int64_t q = j + k * gx, t = x * per + q;
+        return (q < per && t < p.num_tiles) ? t : p.num_tiles;
+    }
+#endif
+    const int64_t t = blockIdx.x + k * (int64_t)gridDim.x;
+    return t < p.num_tiles ? t : p.num_tiles;
+}
+
 // Software pipeline state of the single-asset step kernel: inputs of the current tile, prefetched inputs of the
 // next one, indices of the one after.
 struct PipeState {
@@ -333,7 +349,7 @@ constexpr bool kActionsTwoAhead = sizeof(OT) == 8;
 // iteration may use table tuples loaded before the accounting (`pre`).
 template <typename OT, int VEC, bool FIRST>
 __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, OT *stage, PipeState &ps, int64_t tile,
-                                            int64_t G, int EB, int e, int lane, int wave, PreTuples<OT> pre) {
+                                            int64_t k, int EB, int e, int lane, int wave, PreTuples<OT> pre) {
     const int64_t n0 = tile * EB;
     const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
     account_core<true>(p, l, 1, e, 0, ps.act0, ps.n_cur, ps.n_cur, ps.in_cur, ps.action_cur, p.rew, p.done);
@@ -345,7 +361,7 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
     load_body(p, 1, 0, ps.act1, ps.n_nxt, ps.idx1, ps.spot1, ps.in_nxt);
     if constexpr (!kActionsTwoAhead<OT>)
         if (ps.act1) ps.action_nxt = p.actions[ps.n_nxt];
-    ps.n_nn = pipe_env_of(p, EB, e, tile + 2 * G, ps.act2);
+    ps.n_nn = pipe_env_of(p, EB, e, tile_at(p, k + 2), ps.act2);
     load_head(p, ps.act2, ps.n_nn, ps.idx2, ps.spot2);
     if constexpr (kActionsTwoAhead<OT>)
         if (ps.act2) ps.action_nn = p.actions[ps.n_nn];
@@ -384,7 +400,7 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
     OT *stage = reinterpret_cast<OT *>(smem + wave * kStageBytes);
 
     if constexpr (RESET_ONLY) {
-        for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        for (int64_t k = 0, tile; (tile = tile_at(p, k)) < p.num_tiles; ++k) {
             const int64_t n0 = tile * EB;
             const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
             const int64_t n = n0 + e;
@@ -396,7 +412,7 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
         }
     } else if constexpr (!SINGLE) {
         // multi-asset tiles stream hundreds of KiB each: phase 1 is <1 % of a tile, no pipelining needed
-        for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        for (int64_t k = 0, tile; (tile = tile_at(p, k)) < p.num_tiles; ++k) {
             const int64_t n0 = tile * EB;
             const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
             const bool active = e < ebt;
@@ -478,8 +494,8 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
         // (phase 2, the long part), the state + bar gathers of tile i+1 and the index loads of tile
         // i+2 are already in flight, so only the very first tile pays phase 1's two dependent
         // memory round trips.
-        const int64_t G = gridDim.x;
-        int64_t tile = blockIdx.x;
+        int64_t k = 0;
+        int64_t tile = tile_at(p, 0);
 #if FE_STAMP
         unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.stat_eval);
         if (stamps && tid == 0) {
@@ -490,7 +506,7 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
         PipeState ps;
         ps.action_cur = 0.0f; ps.action_nxt = 0.0f; ps.action_nn = 0.0f;
         ps.n_cur = pipe_env_of(p, EB, e, tile, ps.act0);
-        ps.n_nxt = pipe_env_of(p, EB, e, tile + G, ps.act1);
+        ps.n_nxt = pipe_env_of(p, EB, e, tile_at(p, 1), ps.act1);
         // first tile: everything that needs no index goes out with the index loads (one round trip), only the
         // bar gather (an L2 hit) waits for them
         load_head(p, ps.act0, ps.n_cur, ps.idx1, ps.spot1);
@@ -534,15 +550,15 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
         load_head(p, ps.act1, ps.n_nxt, ps.idx1, ps.spot1);
         // one tile per call; the workgroup's first tile is peeled (FIRST) so that `pre` dies before the loop
         if (tile < p.num_tiles) {
-            single_tile<OT, VEC, true>(p, l, stage, ps, tile, G, EB, e, lane, wave, pre);
+            single_tile<OT, VEC, true>(p, l, stage, ps, tile, k, EB, e, lane, wave, pre);
 #if FE_STAMP
             if (stamps && tid == 0) {
                 stamps[blockIdx.x * 8 + 1] = ps.t_accounted;
                 stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
             }
 #endif
-            for (tile += G; tile < p.num_tiles; tile += G)
-                single_tile<OT, VEC, false>(p, l, stage, ps, tile, G, EB, e, lane, wave, PreTuples<OT>{});
+            for (k = 1; (tile = tile_at(p, k)) < p.num_tiles; ++k)
+                single_tile<OT, VEC, false>(p, l, stage, ps, tile, k, EB, e, lane, wave, PreTuples<OT>{});
         }
 #if FE_STAMP
         if (stamps && tid == 0) {
