@@ -142,3 +142,47 @@ def test_bench_helpers_and_cli_parse_without_a_gpu():
     assert set(bench.CONFIGS) == {1, 2, 3, 4, 5} and bench.CONFIGS[2][1:] == (65536, 1, 64)
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
+
+
+def test_trajectory_state_descriptor_protocol_on_host_tensors():
+    """TrajectoryBuffer(states=True) without a GPU (host_rehearsal): packed layout, begin / state_slot order, the
+    bootstrap row carried into the next chunk, capacity padding, errors."""
+    import torch
+
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    T, N, A, CAP = 4, 5, 2, 7
+    buf = TrajectoryBuffer(T, N, A, device="cpu", host_rehearsal=True, capacity=CAP, states=True)
+    # [rewards f64 (T) | obs_pos f64 (T+1, A) | obs_src i64 (T+1) | actions f32 (T, A) | dones i32 (T)] over CAP envs
+    assert buf._nbytes == CAP * (8 * T + 8 * A * (T + 1) + 8 * (T + 1) + 4 * A * T + 4 * T)
+    assert buf.obs_src.shape == (T + 1, N) and buf.obs_pos.shape == (T + 1, N, A)
+    with pytest.raises(RuntimeError, match="begin"):
+        buf.next_slot()
+        buf.state_slot()
+    buf.clear()
+    desc = lambda k: (torch.arange(N) * 10 + k, torch.full((N, A), float(k), dtype=torch.float64))  # noqa: E731
+    buf.begin(desc(0))
+    with pytest.raises(RuntimeError, match="follows next_slot"):
+        buf.state_slot()
+    for t in range(T):
+        a, r, d = buf.next_slot()
+        a.fill_(t); r.fill_(t); d.zero_()
+        src, pos = buf.state_slot()
+        s2, p2 = desc(t + 1)
+        src.copy_(s2); pos.copy_(p2)
+    assert buf.full()
+    for k in range(T + 1):
+        assert torch.equal(buf.obs_src[k], desc(k)[0]) and torch.equal(buf.obs_pos[k], desc(k)[1])
+    with pytest.raises(RuntimeError, match="start of a chunk"):
+        buf.begin(desc(0))
+    buf.clear()  # row T -> row 0
+    assert torch.equal(buf.obs_src[0], desc(T)[0]) and torch.equal(buf.obs_pos[0], desc(T)[1])
+    buf.mark_filled(2)
+    assert len(buf) == 2
+    with pytest.raises(ValueError):
+        buf.mark_filled(T + 1)
+    plain = TrajectoryBuffer(T, N, A, device="cpu", host_rehearsal=True)
+    for fn in (lambda: plain.begin(desc(0)), plain.state_slot, lambda: plain.states(None, 0), lambda: plain.minibatch_states(None, torch.zeros(1))):
+        with pytest.raises(RuntimeError, match="states=True"):
+            fn()
+    assert plain._nbytes == N * (8 * T + 4 * A * T + 4 * T)  # the compact layout is unchanged without states
