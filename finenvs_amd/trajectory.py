@@ -214,6 +214,8 @@ class TrajectoryBuffer:
         what ``batch_states[mini_batch_indices]`` is in PPO_agent.py:182-186, rendered instead of stored."""
         if not self.has_states:
             raise RuntimeError("this TrajectoryBuffer was built without states=True")
+        if self.t == 0:
+            raise IndexError("the chunk being filled is empty")
         idx = sample_indices.reshape(-1).to(device=self.device, dtype=torch.int64)
         n, t = idx // self.t, idx % self.t
         return env.render(self.obs_src[t, n], self.obs_pos[t, n])
