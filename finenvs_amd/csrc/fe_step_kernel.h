@@ -306,9 +306,15 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
 
 // The k-th tile of this workgroup, or p.num_tiles when it has none left.  Default: grid-strided (tile t -> workgroup
 // t % grid, so t % 8 -- the XCD -- is stable per workgroup).  FE_XCD_BLOCKED (experiment builds): every XCD owns one
-// contiguous eighth of the tiles (tools/placement_modes.hip: plain stores gain 2 - 4 % at 20 GB from that mapping).
+// contiguous eighth of the tiles, = 2: scrambled order (tools/placement_modes.hip: plain stores gain 2 - 4 % at 20 GB from
+// either; the step kernel does not, profiles/r02_microbench/ab_xcd_blocked.txt).
 __device__ __forceinline__ int64_t tile_at(const Params &p, int64_t k) {
-#if FE_XCD_BLOCKED
+#if FE_XCD_BLOCKED == 2
+    {   // scrambled order: a permutation of the tiles (2654435761 is prime and larger than any tile count)
+        const int64_t t = blockIdx.x + k * (int64_t)gridDim.x;
+        return t < p.num_tiles ? (int64_t)(((unsigned long long)t * 2654435761ull) % (unsigned long long)p.num_tiles) : p.num_tiles;
+    }
+#elif FE_XCD_BLOCKED
     const int64_t G = gridDim.x;
     if ((G & 7) == 0) {
         const int64_t x = blockIdx.x & 7, j = blockIdx.x >> 3, gx = G >> 3, per = (p.num_tiles + 7) >> 3;
