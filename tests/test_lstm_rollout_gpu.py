@@ -335,3 +335,43 @@ def test_lstm_rollout_shape_sweep_bit_for_bit(fe, fo):
                     ref.terminated[:] = 0; ref.episode_returns[:] = 0; ref.n_terminated[0] = 0
             cases += 1
     assert cases == 18
+
+
+@pytest.mark.parametrize("N,A,W,H", [(65536, 1, 4, 128), (65536, 1, 64, 32), (16384, 30, 4, 64)])
+def test_lstm_rollout_full_size_sampled_oracle_parity(fe, fo, N, A, W, H):
+    """(env, asset) pairs are independent, so the oracle loop run on a SAMPLE of envs must equal the fused rollout's
+    outputs for those envs at full size (BASELINE config 2's 65 536 envs, with the reference scripts' W = 4 and with
+    config 2's own W = 64; 16 384 envs x 30 sleeves), bit for bit."""
+    from finenvs_amd.data import synthetic
+    from finenvs_amd.rollout import FusedLSTMRollout
+
+    prices, day_id, _ = synthetic.synthetic_series(9, A, 390, 1234)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    D, L, _ = P.shape
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True)
+    rng = np.random.default_rng(N + W)
+    sample = np.unique(np.concatenate([np.arange(40), np.arange(N - 40, N), rng.integers(0, N, 300)]))
+    sidx = torch.from_numpy(sample).to(env.device)
+    spot = torch.from_numpy(rng.integers(0, L - W - 1, N)).to(env.device)
+    spot[sidx[::5]] = L - W - 1 - torch.arange(len(sidx[::5]), device=env.device) % 3  # some right at their episode's end
+    env._spot0.copy_(spot)
+    ref = fo.OracleEnv(P, LR, W, env_indices=env.env_indices[sidx].cpu().numpy(), evaluate=True, nthreads=8)
+    ref.spot0[:] = spot[sidx].cpu().numpy()
+    lstm, lin = _modules(H, seed=H + W)
+    whh, wx, wout, bout = _packed(fo, lstm, lin)
+    roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    obs = ref.reset().copy()
+    K = 3
+    acts, rews, dones = roll.run(K)
+    for k in range(K):
+        a_ref = fo.policy_lstm(obs, whh, wx, wout, bout)
+        obs, r_ref, d_ref, _ = ref.step(a_ref)
+        obs = obs.copy()
+        what = f"N={N} A={A} W={W} H={H} step {k}"
+        assert_bits(t2n(acts[k][sidx]), a_ref, what + " actions")
+        assert_bits(t2n(rews[k][sidx]), r_ref, what + " rewards")
+        assert_bits(t2n(dones[k][sidx]), d_ref, what + " dones")
+    assert_bits(t2n(env.cash[sidx]), ref.cash, "cash")
+    assert_bits(t2n(env.margin[sidx]), ref.margin, "margin")
+    assert_bits(t2n(roll.observation()[sidx]), obs, "observation()")
+    assert int(dones.sum()) > 0
