@@ -182,16 +182,8 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
         const bool active = e < ebt;
         const int64_t n = n0 + e;
         const int64_t sl = n * A + a;
-        SleeveReg st;
-        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
-        st.obs_row = 0; st.obs_pos = 0.0;
+        SleeveReg st = rollout_load_state(p, active, n, sl);
         if (active) {
-            st.idx = p.env_idx[n];
-            st.spot = p.spot0[n];
-            st.cash = p.cash[sl];
-            st.lng = p.lng[sl];
-            st.sht = p.sht[sl];
-            st.margin = p.margin[sl];
             const double pos0 = r.obs_pos[sl];
             l.pos[e * A + a] = pos0;
             if (a == 0) l.src[e] = r.obs_src[n];
@@ -329,17 +321,10 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
             }
             lds_barrier();  // the new observation's descriptors are complete; everyone is done with h_W
         }
-        if (active) {  // state and descriptors go back to HBM once per launch
-            p.cash[sl] = st.cash;
-            p.lng[sl] = st.lng;
-            p.sht[sl] = st.sht;
-            p.margin[sl] = st.margin;
+        rollout_store_state(p, active, a, n, sl, st);  // state and descriptors go back to HBM once per launch
+        if (active) {
             r.obs_pos[sl] = l.pos[e * A + a];
-            if (a == 0) {
-                p.env_idx[n] = st.idx;
-                p.spot0[n] = st.spot;
-                r.obs_src[n] = l.src[e];
-            }
+            if (a == 0) r.obs_src[n] = l.src[e];
         }
         __syncthreads();
     }

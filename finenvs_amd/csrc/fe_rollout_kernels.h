@@ -126,6 +126,35 @@ __device__ __forceinline__ void account_keep(const Params &p, const TileLds &l, 
     }
 }
 
+// A tile's account state moves into registers for the K steps of a fused rollout and goes back to HBM once per launch.
+__device__ __forceinline__ SleeveReg rollout_load_state(const Params &p, bool active, int64_t n, int64_t sl) {
+    SleeveReg st;
+    st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
+    st.obs_row = 0; st.obs_pos = 0.0;
+    if (active) {
+        st.idx = p.env_idx[n];
+        st.spot = p.spot0[n];
+        st.cash = p.cash[sl];
+        st.lng = p.lng[sl];
+        st.sht = p.sht[sl];
+        st.margin = p.margin[sl];
+    }
+    return st;
+}
+
+__device__ __forceinline__ void rollout_store_state(const Params &p, bool active, int a, int64_t n, int64_t sl,
+                                                    const SleeveReg &st) {
+    if (!active) return;
+    p.cash[sl] = st.cash;
+    p.lng[sl] = st.lng;
+    p.sht[sl] = st.sht;
+    p.margin[sl] = st.margin;
+    if (a == 0) {
+        p.env_idx[n] = st.idx;
+        p.spot0[n] = st.spot;
+    }
+}
+
 // ---- f2: K env steps per launch with an in-kernel linear policy ----
 // The policy is the "observation projection" of the north star reduced to its simplest useful
 // form: one weight per (window row, feature), shared by all assets,
@@ -186,16 +215,8 @@ __global__ __launch_bounds__(kBlock, FE_ROLLOUT_WAVES) void fe_rollout_linear_ke
         const bool active = e < ebt;
         const int64_t n = n0 + e;
         const int64_t sl = n * A + a;
-        // the tile's account state moves into registers for the whole K-step loop
-        SleeveReg st;
-        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
+        SleeveReg st = rollout_load_state(p, active, n, sl);
         if (active) {
-            st.idx = p.env_idx[n];
-            st.spot = p.spot0[n];
-            st.cash = p.cash[sl];
-            st.lng = p.lng[sl];
-            st.sht = p.sht[sl];
-            st.margin = p.margin[sl];
             if (a == 0) l.src[e] = r.obs_src[n];
             l.pos[e * A + a] = r.obs_pos[sl];
         }
@@ -235,17 +256,10 @@ __global__ __launch_bounds__(kBlock, FE_ROLLOUT_WAVES) void fe_rollout_linear_ke
                                  r.done_out + (int64_t)k * p.N);
             lds_barrier();  // the new observation's descriptors are complete
         }
-        if (active) {  // state and descriptors go back to HBM once per launch
-            p.cash[sl] = st.cash;
-            p.lng[sl] = st.lng;
-            p.sht[sl] = st.sht;
-            p.margin[sl] = st.margin;
+        rollout_store_state(p, active, a, n, sl, st);  // state and descriptors go back to HBM once per launch
+        if (active) {
             r.obs_pos[sl] = l.pos[e * A + a];
-            if (a == 0) {
-                p.env_idx[n] = st.idx;
-                p.spot0[n] = st.spot;
-                r.obs_src[n] = l.src[e];
-            }
+            if (a == 0) r.obs_src[n] = l.src[e];
         }
         __syncthreads();
     }
@@ -335,16 +349,8 @@ __global__ __launch_bounds__(kBlock) void fe_rollout_table_kernel(const Params p
         const bool active = e < ebt;
         const int64_t n = n0 + e;
         const int64_t sl = n * A + a;
-        SleeveReg st;
-        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
-        st.obs_row = 0; st.obs_pos = 0.0;
+        SleeveReg st = rollout_load_state(p, active, n, sl);
         if (active) {
-            st.idx = p.env_idx[n];
-            st.spot = p.spot0[n];
-            st.cash = p.cash[sl];
-            st.lng = p.lng[sl];
-            st.sht = p.sht[sl];
-            st.margin = p.margin[sl];
             st.obs_row = r.obs_src[n] / (4 * (int64_t)A);
             st.obs_pos = r.obs_pos[sl];
         }
@@ -360,17 +366,10 @@ __global__ __launch_bounds__(kBlock) void fe_rollout_table_kernel(const Params p
                                  r.done_out + (int64_t)k * p.N);
             if constexpr (!SINGLE) lds_barrier();  // LDS scratch of account_keep is reused next step
         }
+        rollout_store_state(p, active, a, n, sl, st);
         if (active) {
-            p.cash[sl] = st.cash;
-            p.lng[sl] = st.lng;
-            p.sht[sl] = st.sht;
-            p.margin[sl] = st.margin;
             r.obs_pos[sl] = st.obs_pos;
-            if (a == 0) {
-                p.env_idx[n] = st.idx;
-                p.spot0[n] = st.spot;
-                r.obs_src[n] = st.obs_row * 4 * (int64_t)A;
-            }
+            if (a == 0) r.obs_src[n] = st.obs_row * 4 * (int64_t)A;
         }
         if constexpr (!SINGLE) __syncthreads();
     }
@@ -570,16 +569,8 @@ __global__ __launch_bounds__(kBlock, 2) void fe_rollout_mlp_kernel(const Params 
         const bool active = e < ebt;
         const int64_t n = n0 + e;
         const int64_t sl = n * A + a;
-        SleeveReg st;
-        st.idx = 0; st.spot = 0; st.cash = 0.0f; st.lng = 0.0f; st.sht = 0.0f; st.margin = 0.0;
-        st.obs_row = 0; st.obs_pos = 0.0;
+        SleeveReg st = rollout_load_state(p, active, n, sl);
         if (active) {
-            st.idx = p.env_idx[n];
-            st.spot = p.spot0[n];
-            st.cash = p.cash[sl];
-            st.lng = p.lng[sl];
-            st.sht = p.sht[sl];
-            st.margin = p.margin[sl];
             if (a == 0) l.src[e] = r.obs_src[n];
             l.pos[e * A + a] = r.obs_pos[sl];
         }
@@ -597,17 +588,10 @@ __global__ __launch_bounds__(kBlock, 2) void fe_rollout_mlp_kernel(const Params 
                                  r.done_out + (int64_t)k * p.N);
             lds_barrier();  // the new observation's descriptors are complete
         }
-        if (active) {  // state and descriptors go back to HBM once per launch
-            p.cash[sl] = st.cash;
-            p.lng[sl] = st.lng;
-            p.sht[sl] = st.sht;
-            p.margin[sl] = st.margin;
+        rollout_store_state(p, active, a, n, sl, st);  // state and descriptors go back to HBM once per launch
+        if (active) {
             r.obs_pos[sl] = l.pos[e * A + a];
-            if (a == 0) {
-                p.env_idx[n] = st.idx;
-                p.spot0[n] = st.spot;
-                r.obs_src[n] = l.src[e];
-            }
+            if (a == 0) r.obs_src[n] = l.src[e];
         }
         __syncthreads();
     }
