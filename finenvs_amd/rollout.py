@@ -85,7 +85,25 @@ class GraphedRollout:
 
 
 class _FusedEvaluation:
-    """Shared by the fused rollouts: the reference's evaluation loop on the device."""
+    """Shared by the fused rollouts (each has ``env``, ``obs_src (N,)``, ``obs_pos (N, A)`` and ``run``): descriptor
+    upkeep, observation on demand, and the reference's evaluation loop on the device."""
+
+    def sync_from_env(self) -> None:
+        """Point the descriptors at the observation ``env.reset()`` would render now."""
+        from . import _lib
+
+        _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                                                 self.env._stream()))
+
+    def observation(self) -> torch.Tensor:
+        """The (N, W, 5A) observation the next policy evaluation will see."""
+        from . import _lib
+
+        obs = self.env._next_obs()
+        _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                                               obs.data_ptr(), self.env._stream()))
+        return obs
+
 
     def evaluate_returns(self, chunk: int = 64, max_steps: int = 1_000_000) -> torch.Tensor:
         """The reference's evaluation loop (examples/time_series/PPO_LSTM_testing_SPY.py:43-52): step the
@@ -158,13 +176,6 @@ class FusedLinearRollout(_FusedEvaluation):
             _lib.check(self.env._lib.fe_policy_table(self.env._handle, self.weights.data_ptr(), self.table.data_ptr(),
                                                      self._wsum.data_ptr(), self.env._stream()))
 
-    def sync_from_env(self) -> None:
-        """Point the descriptors at the observation ``env.reset()`` would render now."""
-        from . import _lib
-
-        _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
-                                                 self.env._stream()))
-
     def run(self, num_steps: int, record_actions: bool = True):
         """Returns (actions (K, N, A) f32 or None, rewards (K, N) f64, dones (K, N) int32)."""
         from . import _lib
@@ -184,15 +195,6 @@ class FusedLinearRollout(_FusedEvaluation):
                 env._handle, self.weights.data_ptr(), self.bias, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
                 actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
         return actions, rewards, dones
-
-    def observation(self) -> torch.Tensor:
-        """The (N, W, 5A) observation the next policy evaluation will see."""
-        from . import _lib
-
-        obs = self.env._next_obs()
-        _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
-                                               obs.data_ptr(), self.env._stream()))
-        return obs
 
 
 class FusedMLPRollout(_FusedEvaluation):
@@ -243,12 +245,6 @@ class FusedMLPRollout(_FusedEvaluation):
         self.w2 = W2.detach().to(dtype=torch.float32, device=dev).reshape(H).contiguous()
         self.b2 = float(b2)
 
-    def sync_from_env(self) -> None:
-        from . import _lib
-
-        _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
-                                                 self.env._stream()))
-
     def run(self, num_steps: int, record_actions: bool = True):
         """Returns (actions (K, N, A) f32 or None, rewards (K, N) f64, dones (K, N) int32)."""
         from . import _lib
@@ -263,15 +259,6 @@ class FusedMLPRollout(_FusedEvaluation):
             self.w2.data_ptr(), self.b2, self.H, self.act, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
             actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
         return actions, rewards, dones
-
-    def observation(self) -> torch.Tensor:
-        """The (N, W, 5A) observation the next policy evaluation will see."""
-        from . import _lib
-
-        obs = self.env._next_obs()
-        _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
-                                               obs.data_ptr(), self.env._stream()))
-        return obs
 
 
 def lstm_row_order(H: int) -> torch.Tensor:
@@ -347,12 +334,6 @@ class FusedLSTMRollout(_FusedEvaluation):
         self.wout = weight_out.detach().to(dtype=torch.float32, device=dev).reshape(H).contiguous()
         self.bout = float(bias_out)
 
-    def sync_from_env(self) -> None:
-        from . import _lib
-
-        _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
-                                                 self.env._stream()))
-
     def run(self, num_steps: int, record_actions: bool = True, noise: Optional[torch.Tensor] = None,
             std: Optional[float] = None, record_means: bool = False, trajectory=None):
         """Returns (actions (K, N, A) f32 or None, rewards (K, N) f64, dones (K, N) int32).
@@ -399,11 +380,3 @@ class FusedLSTMRollout(_FusedEvaluation):
             trajectory.mark_filled(K)
         return actions, rewards, dones
 
-    def observation(self) -> torch.Tensor:
-        """The (N, W, 5A) observation the next policy evaluation will see."""
-        from . import _lib
-
-        obs = self.env._next_obs()
-        _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
-                                               obs.data_ptr(), self.env._stream()))
-        return obs
