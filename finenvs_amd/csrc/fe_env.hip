@@ -587,7 +587,9 @@ int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, 
     if (noise && !(std >= 0.0f)) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: std must be >= 0 when noise is given");
     if (!env || !logret_f32 || !whh || !wx || !wout || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
         return fail(FE_ERR_ARG, "fe_env_rollout_lstm: bad argument");
-    if (H != 32 && H != 64 && H != 128) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: H must be 32, 64 or 128 (got %d)", (int)H);
+    const bool big = H == 256 || H == 512 || H == 1024;  // weights streamed from L2 (fragment-major whh)
+    if (H != 32 && H != 64 && H != 128 && !big)
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: H must be 32, 64, 128, 256, 512 or 1024 (got %d)", (int)H);
     if (out_activation < 0 || out_activation > 1) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: out_activation must be 0 (tanh) or 1 (clamp)");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_lstm: state not bound");
     DeviceGuard guard(env->device);
@@ -597,19 +599,22 @@ int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, 
     r.lr32 = logret_f32; r.whh = whh; r.wx = wx; r.wout = wout; r.bout = bout; r.H = H; r.out_act = out_activation; r.K = K;
     r.obs_src = obs_src; r.obs_pos = obs_pos; r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
     r.noise = noise; r.std = std; r.means_out = means_out; r.traj_src = states_src_out; r.traj_pos = states_pos_out;
-    // SP (env, asset) pairs per workgroup: 2 (H = 128) or 4 column tiles of 32; an env's sleeves stay together
-    const int SP = H == 128 ? LstmGeom<4>::SP : LstmGeom<2>::SP;
+    // SP (env, asset) pairs per workgroup: 1 (H >= 256), 2 (H = 128) or 4 column tiles of 32; an env's sleeves stay together
+    const int SP = big ? 32 : (H == 128 ? LstmGeom<4>::SP : LstmGeom<2>::SP);
     if (p.A > SP)
         return fail(FE_ERR_ARG, "fe_env_rollout_lstm: %d assets per env exceed the %d pairs of a workgroup tile (H = %d)", (int)p.A, SP, (int)H);
     int64_t eb = SP / p.A;
     if (env->rollout_tile_override > 0 && env->rollout_tile_override < eb) eb = env->rollout_tile_override;
     p.EB = (int)eb;
     p.num_tiles = (p.N + eb - 1) / eb;
-    const size_t lds = lstm_lds_bytes(p.EB, p.A, H, SP);
+    const size_t lds = big ? lstm_big_lds_bytes(p.EB, p.A, H) : lstm_lds_bytes(p.EB, p.A, H, SP);
     const bool single = p.A == 1;
 #define FE_LSTM(NT) (single ? (const void *)fe_rollout_lstm_kernel<true, NT> : (const void *)fe_rollout_lstm_kernel<false, NT>)
-    const void *kern = H == 32 ? FE_LSTM(1) : (H == 64 ? FE_LSTM(2) : FE_LSTM(4));
+#define FE_LSTM_BIG(RTW) (single ? (const void *)fe_rollout_lstm_big_kernel<true, RTW> : (const void *)fe_rollout_lstm_big_kernel<false, RTW>)
+    const void *kern = H == 32 ? FE_LSTM(1) : (H == 64 ? FE_LSTM(2) : (H == 128 ? FE_LSTM(4) :
+                       (H == 256 ? FE_LSTM_BIG(4) : (H == 512 ? FE_LSTM_BIG(8) : FE_LSTM_BIG(16)))));
 #undef FE_LSTM
+#undef FE_LSTM_BIG
     hipError_t he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm: hipFuncSetAttribute");
     int per_cu = 0;

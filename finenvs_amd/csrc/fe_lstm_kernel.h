@@ -330,4 +330,201 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
     }
 }
 
+// ---- the same head for H = 256, 512, 1024 (the reference example trains hidden_dim = 1024): weights from L2 ----
+// Whh no longer fits a workgroup's registers (4 MiB / 16 MiB), so it is STREAMED: the host stores it fragment-major --
+// [row tile mt][k group g][lane][4], one contiguous KiB per (mt, g), exactly the A fragment of four MFMAs -- and every
+// wavefront loads its fragments with coalesced 16-byte loads two groups ahead of their use; the XCD's 4 MiB L2 (and the
+// Infinity Cache behind it) serves the 32 CUs that sweep the same matrix.  Per workgroup ONE 32-pair column tile
+// (H = 1024: h alone is 128 KiB of LDS, single-buffered: a wavefront keeps its new h values in registers until every
+// wavefront has finished reading the old ones -- two barriers per time step); each of the 8 wavefronts owns
+// RTW = H / 64 row tiles and runs them two at a time (two independent accumulator chains sharing the B fragment).
+// c_t and the pending h_t live in per-lane scratch (RTW x 4 floats each, touched once per row tile).  Same k order, same activations, same cell update as the register-
+// resident kernel: the same oracle function pins it bit for bit.
+__host__ __device__ inline size_t lstm_big_lds_bytes(int EB, int A, int H) {
+    size_t S = (size_t)EB * A;
+    size_t b = (size_t)EB * 8 + S * 8 + S * 8 + S * 4 + S * 4 + (size_t)EB * 4;  // TileLds
+    b = (b + 7) & ~(size_t)7;
+    b += (size_t)EB * 8;  // redrawn day per env
+    b = (b + 15) & ~(size_t)15;
+    b += (size_t)32 * (H + 4) * 4;  // h, one buffer
+    b += (size_t)H * 4;             // wout
+    return (b + 15) & ~(size_t)15;
+}
+
+template <bool SINGLE, int RTW>
+__global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(const Params p, const LstmArgs r) {
+    constexpr int H = 64 * RTW, HP = H + 4, NG = H / 8, SP = 32;
+    constexpr int AHEAD = 2;  // k groups a weight fragment is loaded ahead of its MFMAs
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const int S = EB * A;
+    const int W = p.W;
+    const TileLds l = carve_lds(smem, EB, S);
+    size_t off = (size_t)EB * 8 + (size_t)S * 8 + (size_t)S * 8 + (size_t)S * 4 + (size_t)S * 4 + (size_t)EB * 4;
+    off = (off + 7) & ~(size_t)7;
+    int64_t *l_idx = reinterpret_cast<int64_t *>(smem + off);
+    off = (off + (size_t)EB * 8 + 15) & ~(size_t)15;
+    float *s_h = reinterpret_cast<float *>(smem + off);  // [SP][HP]
+    float *s_wout = s_h + (size_t)SP * HP;
+    const int tid = threadIdx.x;
+    const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
+    const int a = SINGLE ? 0 : tid - e * A;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int64_t NA = p.N * A;
+    const int64_t rstride = 4 * (int64_t)A;
+    const int mt0 = wave * RTW;  // this wavefront's row tiles: mt0 .. mt0 + RTW - 1
+    for (int i = tid; i < H; i += kLstmBlock) s_wout[i] = r.wout[i];
+
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        const bool active = e < ebt;
+        const int64_t n = n0 + e;
+        const int64_t sl = n * A + a;
+        SleeveReg st = rollout_load_state(p, active, n, sl);
+        if (active) {
+            const double pos0 = r.obs_pos[sl];
+            l.pos[e * A + a] = pos0;
+            if (a == 0) l.src[e] = r.obs_src[n];
+            if (r.traj_src) {
+                r.traj_pos[sl] = pos0;
+                if (a == 0) r.traj_src[n] = r.obs_src[n];
+            }
+        }
+        __syncthreads();  // also covers s_wout on the first tile
+        const int pairs = ebt * A;
+        for (int k = 0; k < r.K; ++k) {
+            const int qc = col < pairs ? col : pairs - 1;
+            const int ee = SINGLE ? qc : (int)fdiv((uint32_t)qc, p.div_A);
+            const int aa = SINGLE ? 0 : qc - ee * A;
+            const float *xsrc = r.lr32 + l.src[ee] + 4 * aa;
+            const float4 xh = make_float4((float)l.pos[qc], 1.0f, 0.0f, 0.0f);
+            float4 xc = half == 0 ? *reinterpret_cast<const float4 *>(xsrc) : xh;
+            float cst[RTW][4], hnew[RTW][4];
+#pragma unroll
+            for (int i = 0; i < RTW; ++i)
+#pragma unroll
+                for (int b = 0; b < 4; ++b) cst[i][b] = 0.0f;
+            for (int t = 0; t < W; ++t) {
+                const int tn = t + 1 < W ? t + 1 : t;
+                const float4 xn = half == 0 ? *reinterpret_cast<const float4 *>(xsrc + (int64_t)tn * rstride) : xh;
+                const float *hrow = s_h + (size_t)col * HP + 4 * half;
+                // a real loop over this wavefront's row-tile pairs: c_t and the pending h_t (RTW x 4 floats each per lane,
+                // touched once per 1040 MFMAs) are indexed dynamically, i.e. live in per-lane scratch, not in VGPRs
+#pragma unroll 1
+                for (int i0 = 0; i0 < RTW; i0 += 2) {
+                    f32x16 acc[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int rr = 0; rr < 16; ++rr) acc[i][rr] = 0.0f;
+                    // input part: four MFMAs per row tile
+                    float4 wxv[2];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        wxv[i] = *reinterpret_cast<const float4 *>(r.wx + ((size_t)32 * (mt0 + i0 + i) + col) * 8 + 4 * half);
+#pragma unroll
+                    for (int m = 0; m < 4; ++m)
+#pragma unroll
+                        for (int i = 0; i < 2; ++i) {
+                            const float xs = m == 0 ? xc.x : (m == 1 ? xc.y : (m == 2 ? xc.z : xc.w));
+                            const float ws = m == 0 ? wxv[i].x : (m == 1 ? wxv[i].y : (m == 2 ? wxv[i].z : wxv[i].w));
+                            acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, acc[i], 0, 0, 0);
+                        }
+                    if (t > 0) {
+                        // fragment-major weights: one coalesced KiB per (row tile, k group), AHEAD groups in flight
+                        const float4 *wf[2];
+#pragma unroll
+                        for (int i = 0; i < 2; ++i)
+                            wf[i] = reinterpret_cast<const float4 *>(r.whh) + ((size_t)(mt0 + i0 + i) * NG) * 64 + lane;
+                        float4 wq[AHEAD][2];
+#pragma unroll
+                        for (int d = 0; d < AHEAD; ++d)
+#pragma unroll
+                            for (int i = 0; i < 2; ++i) wq[d][i] = wf[i][(size_t)d * 64];
+#pragma unroll 1  // a real loop: unrolled, its hoisted loads spill (NG is up to 128 groups of 8 MFMAs)
+                        for (int g0 = 0; g0 < NG; g0 += AHEAD) {
+#pragma unroll
+                            for (int d = 0; d < AHEAD; ++d) {
+                                const int g = g0 + d;
+                                const float4 wv0 = wq[d][0], wv1 = wq[d][1];
+                                const int gn = g + AHEAD < NG ? g + AHEAD : NG - 1;  // (the last loads are redundant, never out of range)
+                                wq[d][0] = wf[0][(size_t)gn * 64];
+                                wq[d][1] = wf[1][(size_t)gn * 64];
+                                const float4 hb = *reinterpret_cast<const float4 *>(hrow + 8 * g);
+#pragma unroll
+                                for (int m = 0; m < 4; ++m) {
+                                    const float hs = m == 0 ? hb.x : (m == 1 ? hb.y : (m == 2 ? hb.z : hb.w));
+                                    const float w0 = m == 0 ? wv0.x : (m == 1 ? wv0.y : (m == 2 ? wv0.z : wv0.w));
+                                    const float w1 = m == 0 ? wv1.x : (m == 1 ? wv1.y : (m == 2 ? wv1.z : wv1.w));
+                                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, hs, acc[0], 0, 0, 0);
+                                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, hs, acc[1], 0, 0, 0);
+                                }
+                            }
+                        }
+                    }
+                    // cell update, in-lane; the new h waits in registers until everyone has read the old one
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        float og[4];
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) {
+                            const v2f sif = lstm_act2<false, false>((v2f){acc[i][4 * b + 0], acc[i][4 * b + 1]});
+                            const v2f tgo = lstm_act2<true, false>((v2f){acc[i][4 * b + 2], acc[i][4 * b + 3]});
+                            const float t1 = sif.y * cst[i0 + i][b];
+                            const float t2 = sif.x * tgo.x;
+                            cst[i0 + i][b] = t1 + t2;
+                            og[b] = tgo.y;
+                        }
+#pragma unroll
+                        for (int b = 0; b < 4; b += 2) {
+                            const v2f tc = lstm_act2<true, true>((v2f){cst[i0 + i][b], cst[i0 + i][b + 1]});
+                            hnew[i0 + i][b] = og[b] * tc.x;
+                            hnew[i0 + i][b + 1] = og[b + 1] * tc.y;
+                        }
+                    }
+                }
+                lds_barrier();  // every wavefront has read h_{t-1}
+#pragma unroll
+                for (int i = 0; i < RTW; ++i)
+                    *reinterpret_cast<float4 *>(s_h + (size_t)col * HP + 8 * (mt0 + i) + 4 * half) =
+                        make_float4(hnew[i][0], hnew[i][1], hnew[i][2], hnew[i][3]);
+                xc = xn;
+                lds_barrier();  // h_t is complete
+            }
+            // ---- output layer: the pair's accounting lane reduces its last hidden state ----
+            float act = 0.0f;
+            if (active) {
+                const float *hl = s_h + (size_t)(e * A + a) * HP;
+                float o = r.bout;
+#pragma unroll 8
+                for (int u = 0; u < H; ++u) o = fmaf(s_wout[u], hl[u], o);
+                act = r.out_act == 0 ? lstm_tanh(o) : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o));
+                if (r.means_out) r.means_out[(int64_t)k * NA + sl] = act;
+                if (r.noise && n != p.eval_env) {
+                    const float dev = r.std * r.noise[(int64_t)k * NA + sl];
+                    const float smp = act + dev;
+                    act = smp < -1.0f ? -1.0f : (smp > 1.0f ? 1.0f : smp);
+                }
+                if (r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
+            }
+            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
+                                 r.done_out + (int64_t)k * p.N);
+            if (active && r.traj_src) {
+                r.traj_pos[(int64_t)(k + 1) * NA + sl] = l.pos[e * A + a];
+                if (a == 0) r.traj_src[(int64_t)(k + 1) * p.N + n] = l.src[e];
+            }
+            lds_barrier();  // the new observation's descriptors are complete; everyone is done with h_W
+        }
+        rollout_store_state(p, active, a, n, sl, st);
+        if (active) {
+            r.obs_pos[sl] = l.pos[e * A + a];
+            if (a == 0) r.obs_src[n] = l.src[e];
+        }
+        __syncthreads();
+    }
+}
+
 }  // namespace

@@ -282,7 +282,9 @@ class FusedLSTMRollout(_FusedEvaluation):
     examples/time_series/PPO_LSTM_testing_SPY.py:43-52 steps the evaluate-mode env with; ``evaluate_returns()`` is
     that loop.  The gate contractions run on the MFMA units in f32, observations are never written to HBM.
     Parameters are ``nn.LSTM``'s ``weight_ih_l0 (4H, 5)``, ``weight_hh_l0 (4H, H)``, ``bias_ih_l0``, ``bias_hh_l0``
-    and the output layer's ``weight (1, H)`` / ``bias``; ``H`` in {32, 64, 128}."""
+    and the output layer's ``weight (1, H)`` / ``bias``; ``H`` in {32, 64, 128} (recurrent weights in registers) or
+    {256, 512, 1024} (streamed from L2; the reference example trains ``hidden_dim=1024``).  The large sizes are a
+    throughput kernel (one 32-pair tile per workgroup walks the whole matrix): worthwhile from ~8k (env, asset) pairs up."""
 
     OUTPUT_ACTIVATIONS = {"tanh": 0, "clamp": 1}
 
@@ -291,8 +293,8 @@ class FusedLSTMRollout(_FusedEvaluation):
         if weight_hh.dim() != 2 or weight_hh.shape[0] != 4 * weight_hh.shape[1]:
             raise ValueError("weight_hh must be (4H, H)")
         H = int(weight_hh.shape[1])
-        if H not in (32, 64, 128):
-            raise ValueError("H must be 32, 64 or 128")
+        if H not in (32, 64, 128, 256, 512, 1024):
+            raise ValueError("H must be 32, 64, 128 (weights in registers) or 256, 512, 1024 (weights streamed from L2)")
         if tuple(weight_ih.shape) != (4 * H, 5):
             raise ValueError(f"weight_ih must be ({4 * H}, 5): the four log-returns and the position feature")
         if output_activation not in self.OUTPUT_ACTIVATIONS:
@@ -329,7 +331,10 @@ class FusedLSTMRollout(_FusedEvaluation):
         wx = torch.zeros((4 * H, 8), dtype=torch.float32)
         wx[:, :5] = w_ih[order]
         wx[:, 5] = bias[order]
-        self.whh = w_hh[order].contiguous().to(dev)
+        whh = w_hh[order].contiguous()  # packed row order
+        if H > 128:  # fragment-major for the streaming kernel: [row tile][k group][lane = (row & 31) + 32 * k half][4]
+            whh = whh.reshape(4 * H // 32, 32, H // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(4 * H, H)
+        self.whh = whh.to(dev)
         self.wx = wx.to(dev)
         self.wout = weight_out.detach().to(dtype=torch.float32, device=dev).reshape(H).contiguous()
         self.bout = float(bias_out)

@@ -229,8 +229,12 @@ int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, c
  * sigmoid / tanh are part of the contract and restated by oracle/fe_oracle.c:fo_policy_lstm (bit-reproducible):
  *   whh (4H, H) f32: weight_hh_l0 with its rows PACKED: row 32*mt + 8*b + 4*half + gate = gate (0 i, 1 f, 2 g, 3 o)
  *   of hidden unit 8*mt + 4*half + b;  wx (4H, 8) f32, same row order: weight_ih_l0[row][0..4], bias_ih + bias_hh,
- *   0, 0;  wout (H), bout: the output layer;  H in {32, 64, 128};  out_activation 0 = tanh, 1 = clamp to [-1, 1].
- * A (assets per env) must not exceed the pairs of a workgroup tile (64 for H = 128, else 128): FE_ERR_ARG.
+ *   0, 0;  wout (H), bout: the output layer;  out_activation 0 = tanh, 1 = clamp to [-1, 1].
+ *   H in {32, 64, 128}: whh row-major as above, held in registers for the whole launch.
+ *   H in {256, 512, 1024} (the reference example trains hidden_dim = 1024): the same packed rows stored FRAGMENT-MAJOR,
+ *   whh[((mt * (H/8) + g) * 64 + lane) * 4 + c] = packed_whh[32*mt + (lane & 31)][8*g + 4*(lane >> 5) + c] -- one
+ *   contiguous KiB per (row tile, k group), streamed from L2 with coalesced loads; same arithmetic, same oracle.
+ * A (assets per env) must not exceed the pairs of a workgroup tile (32 for H >= 256, 64 for H = 128, else 128): FE_ERR_ARG.
  * Training rollouts (finenvs/agents/PPO/PPO_agent.py:98-108, agent.step): with noise (K, N*A) f32 standard-normal
  * draws (made by the caller's generator) and std = exp(log_standard_deviation), the action is
  * clamp(mean + std * noise, -1, 1) (one f32 product, one f32 sum) -- except for the eval env of a training-mode env,

@@ -175,7 +175,7 @@ def test_lstm_rollout_argument_errors(fe, fo):
     ref, env = _make(fe, fo, 10, 1, 4, 5, 40, 0.0, False, seed=1)
     z = torch.zeros
     with pytest.raises(ValueError):
-        FusedLSTMRollout(env, z((4 * 48, 5)), z((4 * 48, 48)), z(4 * 48), z(4 * 48), z(48))      # H not 32/64/128
+        FusedLSTMRollout(env, z((4 * 48, 5)), z((4 * 48, 48)), z(4 * 48), z(4 * 48), z(48))      # H not a supported size
     with pytest.raises(ValueError):
         FusedLSTMRollout(env, z((128, 4)), z((128, 32)), z(128), z(128), z(32))                  # wrong input size
     with pytest.raises(ValueError):
@@ -375,3 +375,47 @@ def test_lstm_rollout_full_size_sampled_oracle_parity(fe, fo, N, A, W, H):
     assert_bits(t2n(env.margin[sidx]), ref.margin, "margin")
     assert_bits(t2n(roll.observation()[sidx]), obs, "observation()")
     assert int(dones.sum()) > 0
+
+
+@pytest.mark.parametrize("N,A,W,H,sample", [
+    (70, 1, 4, 256, False),     # weights streamed from L2: 4 row tiles per wavefront; 70 = two full tiles + 6 pairs
+    (21, 3, 3, 512, True),      # 3 sleeves: 10 envs per 32-pair tile (30 pairs), sampled actions
+    (33, 1, 4, 1024, False),    # the reference example's hidden_dim = 1024 (PPO_LSTM_training_SPY.py:16, testing:28)
+    (4, 30, 2, 256, False),     # 30 sleeves: one env per tile
+])
+def test_lstm_rollout_large_hidden_sizes_bit_for_bit(fe, fo, N, A, W, H, sample):
+    """H = 256 / 512 / 1024: the recurrent weights no longer fit a workgroup's registers and are streamed from L2 in
+    fragment-major order (fe_rollout_lstm_big_kernel) -- same k order, same activations, same oracle: bit for bit."""
+    from finenvs_amd.rollout import FusedLSTMRollout
+
+    ref, env = _make(fe, fo, N, A, W, 6, 30, 0.05, False, seed=N + H)
+    lstm, lin = _modules(H, seed=H, gain=2.0)
+    whh, wx, wout, bout = _packed(fo, lstm, lin)
+    roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    # the device copy is fragment-major: [row tile][k group][lane][4] of the same packed rows
+    frag = whh.reshape(4 * H // 32, 32, H // 8, 2, 4).transpose(0, 2, 3, 1, 4).reshape(4 * H, H)
+    assert_bits(t2n(roll.whh), np.ascontiguousarray(frag), "fragment-major Whh")
+    obs = ref.reset().copy()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    std = np.float32(0.5)
+    seen = set()
+    for rep in range(3):
+        K = 4
+        noise = torch.randn((K, N, A), generator=g, device="cuda") if sample else None
+        acts, rews, dones = roll.run(K, noise=noise, std=float(std) if sample else None)
+        for k in range(K):
+            a_ref = fo.policy_lstm(obs, whh, wx, wout, bout)
+            seen.update(np.unique(np.round(a_ref, 2)).tolist())
+            if sample:
+                smp = np.clip((a_ref + (std * t2n(noise[k])).astype(np.float32)).astype(np.float32), np.float32(-1), np.float32(1))
+                smp[N - 1] = a_ref[N - 1]
+                a_ref = smp
+            obs, r_ref, d_ref, _ = ref.step(a_ref)
+            obs = obs.copy()
+            what = f"H={H} rep {rep} step {k}"
+            assert_bits(t2n(acts[k]), a_ref, what + " actions")
+            assert_bits(t2n(rews[k]), r_ref, what + " rewards")
+            assert_bits(t2n(dones[k]), d_ref, what + " dones")
+        assert_bits(t2n(env.cash), ref.cash, f"rep {rep} cash")
+        assert_bits(t2n(roll.observation()), obs, f"rep {rep} observation()")
+    assert len(seen) > 5, "the policy's outputs must vary across envs"

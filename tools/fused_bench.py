@@ -2,8 +2,8 @@
 linear window form, linear table form, MLP head and LSTM head on the matrix cores.
 
     python tools/fused_bench.py <config> [form ...]      forms: window table mlp32 mlp64 mlp128 lstm32 lstm64 lstm128
-    FUSED_W=4 overrides the config's window (the reference's LSTM scripts use num_intervals=4), FUSED_K the steps per
-    launch, FUSED_TILES a list of rollout tile overrides.
+    FUSED_W=4 overrides the config's window (the reference's LSTM scripts use num_intervals=4), FUSED_N the env count,
+    FUSED_K the steps per launch, FUSED_TILES a list of rollout tile overrides.
 """
 import os
 import sys
@@ -19,6 +19,7 @@ cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 forms = sys.argv[2:] or ["window", "table", "mlp32", "mlp64"]
 name, N, A, W = CONFIGS[cfg]
 W = int(os.environ.get("FUSED_W", W))
+N = int(os.environ.get("FUSED_N", N))  # e.g. an evaluation over a few thousand trading days
 prices, day_id, _ = make_series(A)
 K = int(os.environ.get("FUSED_K", "32"))
 tiles = [int(x) for x in os.environ.get("FUSED_TILES", "0").split(",")]
