@@ -114,7 +114,7 @@ if __name__ == "__main__":
     ap.add_argument("--envs", type=int, default=4096)
     ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--iters", type=int, default=5)
-    ap.add_argument("--hidden", type=int, default=64, choices=[32, 64, 128])
+    ap.add_argument("--hidden", type=int, default=64, choices=[32, 64, 128, 256, 512, 1024])
     ap.add_argument("--window", type=int, default=4)
     a = ap.parse_args()
     main(a.envs, a.steps, a.iters, a.hidden, a.window)
