@@ -354,7 +354,7 @@ __host__ __device__ inline size_t lstm_big_lds_bytes(int EB, int A, int H) {
 template <bool SINGLE, int RTW>
 __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(const Params p, const LstmArgs r) {
     constexpr int H = 64 * RTW, HP = H + 4, NG = H / 8, SP = 32;
-    constexpr int AHEAD = 2;  // k groups a weight fragment is loaded ahead of its MFMAs
+    constexpr int AHEAD = 4;  // k groups a weight fragment is loaded ahead of its MFMAs
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
@@ -375,6 +375,8 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
     const int64_t NA = p.N * A;
     const int64_t rstride = 4 * (int64_t)A;
     const int mt0 = wave * RTW;  // this wavefront's row tiles: mt0 .. mt0 + RTW - 1
+    float4 wq[AHEAD][2];  // weight fragments in flight (see the k loop)
+    bool primed = false;
     for (int i = tid; i < H; i += kLstmBlock) s_wout[i] = r.wout[i];
 
     for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
@@ -434,25 +436,32 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, acc[i], 0, 0, 0);
                         }
                     if (t > 0) {
-                        // fragment-major weights: one coalesced KiB per (row tile, k group), AHEAD groups in flight
-                        const float4 *wf[2];
+                        // fragment-major weights: one coalesced KiB per (row tile, k group), AHEAD groups in flight -- across
+                        // row-tile pairs and time steps too: the tail of one k loop already fetches the head of the next
+                        // (the next pair's, or after the last pair the first pair's again: the matrix never changes)
+                        const float4 *wbase = reinterpret_cast<const float4 *>(r.whh) + lane;
+                        const float4 *wf[2], *wfn[2];
 #pragma unroll
-                        for (int i = 0; i < 2; ++i)
-                            wf[i] = reinterpret_cast<const float4 *>(r.whh) + ((size_t)(mt0 + i0 + i) * NG) * 64 + lane;
-                        float4 wq[AHEAD][2];
+                        for (int i = 0; i < 2; ++i) {
+                            wf[i] = wbase + ((size_t)(mt0 + i0 + i) * NG) * 64;
+                            wfn[i] = wbase + ((size_t)(mt0 + (i0 + 2 < RTW ? i0 + 2 : 0) + i) * NG) * 64;
+                        }
+                        if (!primed) {
 #pragma unroll
-                        for (int d = 0; d < AHEAD; ++d)
+                            for (int d = 0; d < AHEAD; ++d)
 #pragma unroll
-                            for (int i = 0; i < 2; ++i) wq[d][i] = wf[i][(size_t)d * 64];
+                                for (int i = 0; i < 2; ++i) wq[d][i] = wf[i][(size_t)d * 64];
+                            primed = true;
+                        }
 #pragma unroll 1  // a real loop: unrolled, its hoisted loads spill (NG is up to 128 groups of 8 MFMAs)
                         for (int g0 = 0; g0 < NG; g0 += AHEAD) {
 #pragma unroll
                             for (int d = 0; d < AHEAD; ++d) {
                                 const int g = g0 + d;
                                 const float4 wv0 = wq[d][0], wv1 = wq[d][1];
-                                const int gn = g + AHEAD < NG ? g + AHEAD : NG - 1;  // (the last loads are redundant, never out of range)
-                                wq[d][0] = wf[0][(size_t)gn * 64];
-                                wq[d][1] = wf[1][(size_t)gn * 64];
+                                const int gn = g + AHEAD;
+                                wq[d][0] = gn < NG ? wf[0][(size_t)gn * 64] : wfn[0][(size_t)(gn - NG) * 64];
+                                wq[d][1] = gn < NG ? wf[1][(size_t)gn * 64] : wfn[1][(size_t)(gn - NG) * 64];
                                 const float4 hb = *reinterpret_cast<const float4 *>(hrow + 8 * g);
 #pragma unroll
                                 for (int m = 0; m < 4; ++m) {
