@@ -23,8 +23,8 @@ asynchronous trajectory all-gather (the headline `value`; one whole gather per t
 After the headline workload (BASELINE.json's "64k envs" configuration) the same process runs
 the larger BASELINE configs for a few steps each and reports them under "extra_configs" -- on
 one GPU configs 3 and 4 (the 1M-env north-star run), on N > 1 GPUs the per-GPU shard of
-config 5 (4M envs over 8 GPUs); at N = 1 also three fused-rollout legs ("fused_rollouts": K steps per launch
-with an in-kernel linear / MLP / LSTM policy; never part of `value`).  Prints ONE JSON line on rank 0.
+config 5 (4M envs over 8 GPUs); at N = 1 also four fused-rollout legs ("fused_rollouts": K steps per launch
+with an in-kernel linear / MLP / LSTM (H = 128, 1024) policy; never part of `value`).  Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -482,7 +482,7 @@ def fused_rollout_legs(args):
     prices, day_id, _ = make_series(A)
     g = torch.Generator().manual_seed(0)
     legs = []
-    for form, W, K in (("linear_table", 64, 32), ("mlp_h64", 64, 32), ("lstm_h128", 4, 8)):
+    for form, W, K in (("linear_table", 64, 32), ("mlp_h64", 64, 32), ("lstm_h128", 4, 8), ("lstm_h1024", 4, 2)):
         try:
             env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw=args.redraw,
                                             seed=1234, obs_buffers=1)
@@ -497,14 +497,15 @@ def fused_rollout_legs(args):
                 flop = 2.0 * N * A * (4 * W) * H
                 policy = "Linear(5W, 64) -> ELU -> Linear(64, 1), first layer on v_mfma_f32_32x32x2_f32"
             else:
-                H = 128
+                H = int(form.split("_h")[1])
                 torch.manual_seed(0)
                 lstm, lin = torch.nn.LSTM(5, H, batch_first=True), torch.nn.Linear(H, 1)
                 with torch.no_grad():
                     lstm.weight_ih_l0[:, :4].mul_(6.0 * H ** 0.5)
                 roll = FusedLSTMRollout.from_modules(env, lstm, lin)
                 flop = 2.0 * N * A * 4 * H * (8 * W + H * (W - 1))
-                policy = "the reference's actor: LSTM(5, 128) over the W rows -> Linear(128, 1) -> tanh, gates on v_mfma_f32_32x32x2_f32"
+                policy = (f"the reference's actor: LSTM(5, {H}) over the W rows -> Linear({H}, 1) -> tanh, gates on v_mfma_f32_32x32x2_f32"
+                          + (", recurrent weights streamed from L2 (the reference example's hidden_dim)" if H > 128 else ", recurrent weights in registers"))
             roll.run(K, record_actions=True)
             times = []
             for _ in range(3):
