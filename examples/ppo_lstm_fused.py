@@ -11,7 +11,7 @@ like finenvs/agents/PPO/{PPO_agent,continuous_actor,critic}.py.
 What runs where:
     rollout   : FusedLSTMRollout.run(K, noise, std, trajectory)       one launch per K steps, nothing written but
                                                                        actions / rewards / dones / descriptors
-    values    : critic(render(states)) in minibatches                 the critic is not in the env loop
+    values    : FusedLSTMRollout(..., "none").forward(descriptors)    all (K + 1) x N states in one launch, no observations
     returns   : TrajectoryBuffer.returns_and_advantages               one reverse-scan kernel (buffer.py:80-100)
     update    : torch autograd on minibatches rendered from descriptors (PPO_agent.py:175-196)
 """
@@ -59,6 +59,7 @@ def main(envs=4096, steps=16, iters=5, hidden=64, window=4, epochs=2, minibatche
     traj = TrajectoryBuffer(steps, envs, 1, states=True)
     stats = EpisodeStats(env)
     roll = FusedLSTMRollout.from_modules(env, actor.lstm, actor.last)
+    value_head = FusedLSTMRollout.from_modules(env, critic.lstm, critic.last, output_activation="none")
     gen = torch.Generator(device=dev).manual_seed(seed)
     clip, ent_coef, gamma = 0.2, 0.01, 0.99
     history = []
@@ -70,8 +71,8 @@ def main(envs=4096, steps=16, iters=5, hidden=64, window=4, epochs=2, minibatche
         actions, rewards, dones = roll.run(steps, noise=noise, std=std, record_means=True, trajectory=traj)
         with torch.no_grad():
             old_logp = torch.distributions.Normal(roll.means, std).log_prob(actions)           # (K, N, 1)
-            # ---- values of the K stored states and of the bootstrap state: the critic on rendered states ----
-            values = torch.stack([critic(traj.states(env, t)).squeeze(-1) for t in range(steps + 1)])  # (K+1, N)
+            # ---- values of the K stored states and of the bootstrap state: the critic on their descriptors ----
+            values = value_head.forward(traj.obs_src, traj.obs_pos).reshape(steps + 1, envs)          # (K+1, N)
             returns, advantages = traj.returns_and_advantages(values[:steps], values[steps], gamma)     # (K, N) f32
         # ---- update: minibatches rendered from the descriptors (sample = env * steps + step, buffer.py:102-109) ----
         total = envs * steps
@@ -93,8 +94,9 @@ def main(envs=4096, steps=16, iters=5, hidden=64, window=4, epochs=2, minibatche
                 opt_c.zero_grad()
                 loss_c.backward()
                 opt_c.step()
-        roll.set_weights(actor.lstm.weight_ih_l0, actor.lstm.weight_hh_l0, actor.lstm.bias_ih_l0, actor.lstm.bias_hh_l0,
-                         actor.last.weight, float(actor.last.bias.detach()))
+        for head, net in ((roll, actor), (value_head, critic)):  # the updated networks go back into the kernels
+            head.set_weights(net.lstm.weight_ih_l0, net.lstm.weight_hh_l0, net.lstm.bias_ih_l0, net.lstm.bias_hh_l0,
+                             net.last.weight, float(net.last.bias.detach()))
         traj.clear()
         log = stats.read(reset=True)
         history.append((float(loss_c.detach()), float(rewards.mean()), log))

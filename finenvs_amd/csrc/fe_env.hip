@@ -578,31 +578,21 @@ int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, c
     return FE_OK;
 }
 
-int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout,
-                        float bout, int32_t H, int32_t out_activation, int32_t K, int64_t *obs_src, double *obs_pos,
-                        const float *noise, float std, float *actions_out, float *means_out, double *rewards_out,
-                        int32_t *dones_out, int64_t *states_src_out, double *states_pos_out, void *stream) {
-    if ((states_src_out == nullptr) != (states_pos_out == nullptr))
-        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: states_src_out and states_pos_out go together");
-    if (noise && !(std >= 0.0f)) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: std must be >= 0 when noise is given");
-    if (!env || !logret_f32 || !whh || !wx || !wout || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
-        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: bad argument");
+// Shared by fe_env_rollout_lstm and fe_lstm_forward: geometry, kernel choice, launch.  `count` = envs (rollout) or
+// descriptors (forward).
+static int launch_lstm(fe_env *env, LstmArgs &r, int64_t count, const char *who, void *stream) {
+    const int32_t H = r.H;
     const bool big = H == 256 || H == 512 || H == 1024;  // weights streamed from L2 (fragment-major whh)
     if (H != 32 && H != 64 && H != 128 && !big)
-        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: H must be 32, 64, 128, 256, 512 or 1024 (got %d)", (int)H);
-    if (out_activation < 0 || out_activation > 1) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: out_activation must be 0 (tanh) or 1 (clamp)");
-    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_lstm: state not bound");
+        return fail(FE_ERR_ARG, "%s: H must be 32, 64, 128, 256, 512 or 1024 (got %d)", who, (int)H);
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     Params p = env->p;
-    LstmArgs r;
-    r.lr32 = logret_f32; r.whh = whh; r.wx = wx; r.wout = wout; r.bout = bout; r.H = H; r.out_act = out_activation; r.K = K;
-    r.obs_src = obs_src; r.obs_pos = obs_pos; r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
-    r.noise = noise; r.std = std; r.means_out = means_out; r.traj_src = states_src_out; r.traj_pos = states_pos_out;
+    p.N = count;
     // SP (env, asset) pairs per workgroup: 1 (H >= 256), 2 (H = 128) or 4 column tiles of 32; an env's sleeves stay together
     const int SP = big ? 32 : (H == 128 ? LstmGeom<4>::SP : LstmGeom<2>::SP);
     if (p.A > SP)
-        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: %d assets per env exceed the %d pairs of a workgroup tile (H = %d)", (int)p.A, SP, (int)H);
+        return fail(FE_ERR_ARG, "%s: %d assets per env exceed the %d pairs of a workgroup tile (H = %d)", who, (int)p.A, SP, (int)H);
     int64_t eb = SP / p.A;
     if (env->rollout_tile_override > 0 && env->rollout_tile_override < eb) eb = env->rollout_tile_override;
     p.EB = (int)eb;
@@ -616,17 +606,53 @@ int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, 
 #undef FE_LSTM
 #undef FE_LSTM_BIG
     hipError_t he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm: hipFuncSetAttribute");
+    if (he != hipSuccess) return hip_fail(he, "hipFuncSetAttribute (LSTM kernel)");
     int per_cu = 0;
     he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kLstmBlock, lds);
-    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm: hipOccupancyMaxActiveBlocksPerMultiprocessor");
+    if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor (LSTM kernel)");
     if (per_cu < 1) per_cu = 1;
-    const int64_t resident = (int64_t)env->cus * per_cu;  // the weights sit in registers: one pass of resident workgroups
+    const int64_t resident = (int64_t)env->cus * per_cu;  // one pass of resident workgroups, each looping over its tiles
     const int64_t grid = p.num_tiles < resident ? p.num_tiles : resident;
     void *args[] = {&p, &r};
     he = hipLaunchKernel(kern, dim3((unsigned)grid), dim3(kLstmBlock), args, lds, (hipStream_t)stream);
-    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm launch");
+    if (he != hipSuccess) return hip_fail(he, "LSTM kernel launch");
     return FE_OK;
+}
+
+int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout,
+                        float bout, int32_t H, int32_t out_activation, int32_t K, int64_t *obs_src, double *obs_pos,
+                        const float *noise, float std, float *actions_out, float *means_out, double *rewards_out,
+                        int32_t *dones_out, int64_t *states_src_out, double *states_pos_out, void *stream) {
+    if ((states_src_out == nullptr) != (states_pos_out == nullptr))
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: states_src_out and states_pos_out go together");
+    if (noise && !(std >= 0.0f)) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: std must be >= 0 when noise is given");
+    if (!env || !logret_f32 || !whh || !wx || !wout || !obs_src || !obs_pos || !rewards_out || !dones_out || K < 1)
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm: bad argument");
+    if (out_activation < 0 || out_activation > 1) return fail(FE_ERR_ARG, "fe_env_rollout_lstm: out_activation must be 0 (tanh) or 1 (clamp)");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_lstm: state not bound");
+    LstmArgs r;
+    r.lr32 = logret_f32; r.whh = whh; r.wx = wx; r.wout = wout; r.bout = bout; r.H = H; r.out_act = out_activation; r.K = K;
+    r.obs_src = obs_src; r.obs_pos = obs_pos; r.actions_out = actions_out; r.rew_out = rewards_out; r.done_out = dones_out;
+    r.noise = noise; r.std = std; r.means_out = means_out; r.traj_src = states_src_out; r.traj_pos = states_pos_out;
+    r.forward_only = 0;
+    return launch_lstm(env, r, env->cfg.N, "fe_env_rollout_lstm", stream);
+}
+
+int fe_lstm_forward(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout, float bout,
+                    int32_t H, int32_t out_activation, const int64_t *obs_src, const double *obs_pos, int64_t count,
+                    float *out, void *stream) {
+    if (!env || !logret_f32 || !whh || !wx || !wout || !obs_src || !obs_pos || !out || count < 0)
+        return fail(FE_ERR_ARG, "fe_lstm_forward: bad argument");
+    if (out_activation < 0 || out_activation > 2)
+        return fail(FE_ERR_ARG, "fe_lstm_forward: out_activation must be 0 (tanh), 1 (clamp) or 2 (none)");
+    if (count == 0) return FE_OK;
+    LstmArgs r;
+    r.lr32 = logret_f32; r.whh = whh; r.wx = wx; r.wout = wout; r.bout = bout; r.H = H; r.out_act = out_activation; r.K = 1;
+    r.obs_src = const_cast<int64_t *>(obs_src); r.obs_pos = const_cast<double *>(obs_pos);  // read only in this mode
+    r.actions_out = out; r.rew_out = nullptr; r.done_out = nullptr;
+    r.noise = nullptr; r.std = 0.0f; r.means_out = nullptr; r.traj_src = nullptr; r.traj_pos = nullptr;
+    r.forward_only = 1;
+    return launch_lstm(env, r, count, "fe_lstm_forward", stream);
 }
 
 int fe_lstm_activations(const float *x, float *sigmoid_out, float *tanh_out, int64_t n, void *stream) {

@@ -31,7 +31,7 @@ struct LstmArgs {
     const float *wx;    // (4H, 8) f32, packed row order: w_ih[0..3], w_ih[4], b_ih + b_hh, 0, 0
     const float *wout;  // (H)
     float bout;
-    int32_t H, out_act, K;  // out_act: 0 tanh (the reference's actor), 1 clamp to [-1, 1]
+    int32_t H, out_act, K;  // out_act: 0 tanh (the reference's actor), 1 clamp to [-1, 1], 2 none (a critic's value)
     int64_t *obs_src;
     double *obs_pos;
     float *actions_out;
@@ -43,6 +43,7 @@ struct LstmArgs {
     float *means_out;    // (K, N*A) or null
     int64_t *traj_src;   // (K + 1, N) or null: descriptors of the state the policy sees at every step (+ the last one)
     double *traj_pos;    // (K + 1, N*A)
+    int32_t forward_only;  // fe_lstm_forward: evaluate the head on p.N given descriptors, no env step (K = 1, actions_out = the outputs)
 };
 
 template <int NT> struct LstmGeom {
@@ -182,7 +183,7 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
         const bool active = e < ebt;
         const int64_t n = n0 + e;
         const int64_t sl = n * A + a;
-        SleeveReg st = rollout_load_state(p, active, n, sl);
+        SleeveReg st = rollout_load_state(p, active && !r.forward_only, n, sl);
         if (active) {
             const double pos0 = r.obs_pos[sl];
             l.pos[e * A + a] = pos0;
@@ -304,7 +305,7 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
                 float o = r.bout;
 #pragma unroll 8
                 for (int u = 0; u < H; ++u) o = fmaf(s_wout[u], hl[u], o);
-                act = r.out_act == 0 ? lstm_tanh(o) : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o));
+                act = r.out_act == 0 ? lstm_tanh(o) : (r.out_act == 2 ? o : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o)));
                 if (r.means_out) r.means_out[(int64_t)k * NA + sl] = act;
                 if (r.noise && n != p.eval_env) {  // distribution.sample() clamped; the eval env keeps the mean
                     const float dev = r.std * r.noise[(int64_t)k * NA + sl];
@@ -313,18 +314,22 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
                 }
                 if (r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
             }
-            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
-                                 r.done_out + (int64_t)k * p.N);
-            if (active && r.traj_src) {  // row k + 1: the observation this step returns (own LDS entries: no barrier needed)
-                r.traj_pos[(int64_t)(k + 1) * NA + sl] = l.pos[e * A + a];
-                if (a == 0) r.traj_src[(int64_t)(k + 1) * p.N + n] = l.src[e];
+            if (!r.forward_only) {  // (uniform)
+                account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
+                                     r.done_out + (int64_t)k * p.N);
+                if (active && r.traj_src) {  // row k + 1: the observation this step returns (own LDS entries: no barrier needed)
+                    r.traj_pos[(int64_t)(k + 1) * NA + sl] = l.pos[e * A + a];
+                    if (a == 0) r.traj_src[(int64_t)(k + 1) * p.N + n] = l.src[e];
+                }
             }
             lds_barrier();  // the new observation's descriptors are complete; everyone is done with h_W
         }
-        rollout_store_state(p, active, a, n, sl, st);  // state and descriptors go back to HBM once per launch
-        if (active) {
-            r.obs_pos[sl] = l.pos[e * A + a];
-            if (a == 0) r.obs_src[n] = l.src[e];
+        if (!r.forward_only) {
+            rollout_store_state(p, active, a, n, sl, st);  // state and descriptors go back to HBM once per launch
+            if (active) {
+                r.obs_pos[sl] = l.pos[e * A + a];
+                if (a == 0) r.obs_src[n] = l.src[e];
+            }
         }
         __syncthreads();
     }
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
         const bool active = e < ebt;
         const int64_t n = n0 + e;
         const int64_t sl = n * A + a;
-        SleeveReg st = rollout_load_state(p, active, n, sl);
+        SleeveReg st = rollout_load_state(p, active && !r.forward_only, n, sl);
         if (active) {
             const double pos0 = r.obs_pos[sl];
             l.pos[e * A + a] = pos0;
@@ -510,7 +515,7 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
                 float o = r.bout;
 #pragma unroll 8
                 for (int u = 0; u < H; ++u) o = fmaf(s_wout[u], hl[u], o);
-                act = r.out_act == 0 ? lstm_tanh(o) : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o));
+                act = r.out_act == 0 ? lstm_tanh(o) : (r.out_act == 2 ? o : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o)));
                 if (r.means_out) r.means_out[(int64_t)k * NA + sl] = act;
                 if (r.noise && n != p.eval_env) {
                     const float dev = r.std * r.noise[(int64_t)k * NA + sl];
@@ -519,18 +524,22 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
                 }
                 if (r.actions_out) r.actions_out[(int64_t)k * NA + sl] = act;
             }
-            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
-                                 r.done_out + (int64_t)k * p.N);
-            if (active && r.traj_src) {
-                r.traj_pos[(int64_t)(k + 1) * NA + sl] = l.pos[e * A + a];
-                if (a == 0) r.traj_src[(int64_t)(k + 1) * p.N + n] = l.src[e];
+            if (!r.forward_only) {  // (uniform)
+                account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out + (int64_t)k * p.N,
+                                     r.done_out + (int64_t)k * p.N);
+                if (active && r.traj_src) {
+                    r.traj_pos[(int64_t)(k + 1) * NA + sl] = l.pos[e * A + a];
+                    if (a == 0) r.traj_src[(int64_t)(k + 1) * p.N + n] = l.src[e];
+                }
             }
             lds_barrier();  // the new observation's descriptors are complete; everyone is done with h_W
         }
-        rollout_store_state(p, active, a, n, sl, st);
-        if (active) {
-            r.obs_pos[sl] = l.pos[e * A + a];
-            if (a == 0) r.obs_src[n] = l.src[e];
+        if (!r.forward_only) {
+            rollout_store_state(p, active, a, n, sl, st);
+            if (active) {
+                r.obs_pos[sl] = l.pos[e * A + a];
+                if (a == 0) r.obs_src[n] = l.src[e];
+            }
         }
         __syncthreads();
     }

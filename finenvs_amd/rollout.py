@@ -286,7 +286,7 @@ class FusedLSTMRollout(_FusedEvaluation):
     {256, 512, 1024} (streamed from L2; the reference example trains ``hidden_dim=1024``).  The large sizes are a
     throughput kernel (one 32-pair tile per workgroup walks the whole matrix): worthwhile from ~8k (env, asset) pairs up."""
 
-    OUTPUT_ACTIVATIONS = {"tanh": 0, "clamp": 1}
+    OUTPUT_ACTIVATIONS = {"tanh": 0, "clamp": 1, "none": 2}  # "none": a critic (forward() only; an action needs bounds)
 
     def __init__(self, env, weight_ih: torch.Tensor, weight_hh: torch.Tensor, bias_ih: torch.Tensor, bias_hh: torch.Tensor,
                  weight_out: torch.Tensor, bias_out: float = 0.0, output_activation: str = "tanh"):
@@ -338,6 +338,28 @@ class FusedLSTMRollout(_FusedEvaluation):
         self.wx = wx.to(dev)
         self.wout = weight_out.detach().to(dtype=torch.float32, device=dev).reshape(H).contiguous()
         self.bout = float(bias_out)
+
+    def forward(self, obs_src: torch.Tensor, obs_pos: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The head evaluated on ANY B observation descriptors (``obs_src (B,)`` int64, ``obs_pos (B, A)`` float64 --
+        rows of a ``TrajectoryBuffer(states=True)``, gathered ones included) without stepping the env and without
+        materialising the observations: ``(B, A)`` float32.  With ``output_activation="none"`` this is the critic of the
+        reference's PPO (finenvs/agents/PPO/critic.py, CriticLSTM): the values of all K + 1 states of a chunk in one
+        launch, e.g. ``critic.forward(traj.obs_src, traj.obs_pos).reshape(K + 1, N)``."""
+        from . import _lib
+
+        env, A = self.env, self.env.num_assets
+        B = int(obs_src.numel())
+        src = obs_src.reshape(B).to(device=env._dev, dtype=torch.int64).contiguous()
+        pos = obs_pos.reshape(B, A).to(device=env._dev, dtype=torch.float64).contiguous()
+        if out is None:
+            out = torch.empty((B, A), dtype=torch.float32, device=env._dev)
+        elif out.dtype is not torch.float32 or out.numel() != B * A or not out.is_contiguous() or out.device != env._dev:
+            raise ValueError(f"out must be a contiguous float32 tensor of {B} x {A} elements on {env._dev}")
+        if B:
+            _lib.check(env._lib.fe_lstm_forward(
+                env._handle, self._lr32.data_ptr(), self.whh.data_ptr(), self.wx.data_ptr(), self.wout.data_ptr(), self.bout,
+                self.H, self.out_act, src.data_ptr(), pos.data_ptr(), B, out.data_ptr(), env._stream()))
+        return out
 
     def run(self, num_steps: int, record_actions: bool = True, noise: Optional[torch.Tensor] = None,
             std: Optional[float] = None, record_means: bool = False, trajectory=None):

@@ -249,6 +249,18 @@ int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, 
                         const float *noise, float std, float *actions_out, float *means_out, double *rewards_out,
                         int32_t *dones_out, int64_t *states_src_out, double *states_pos_out, void *stream);
 
+/*
+ * The same LSTM head (same weights layout, same arithmetic) evaluated on ANY `count` observation descriptors without
+ * stepping an env and without materialising the observations: out (count*A) f32.  out_activation 2 = none -- a critic
+ * (finenvs/agents/PPO/critic.py, CriticLSTM: LSTMNetwork with the Identity output) -- so the values of all K + 1
+ * states of a trajectory chunk (PPO_agent.py:99, 171) are one launch over its descriptor rows.  The env's state is not
+ * read or written; obs_src (count) i64, obs_pos (count*A) f64 as produced by fe_env_describe / fe_env_step_traj /
+ * fe_env_rollout_lstm (states_*_out).
+ */
+int fe_lstm_forward(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout, float bout,
+                    int32_t H, int32_t out_activation, const int64_t *obs_src, const double *obs_pos, int64_t count,
+                    float *out, void *stream);
+
 /* Diagnostics: the sigmoid and tanh fe_env_rollout_lstm applies to nn.LSTM's gates (finenvs/agents/networks/lstm.py:28-34)
  * and to the actor's output (continuous_actor.py:112), elementwise on n device floats: pins them against the oracle. */
 int fe_lstm_activations(const float *x, float *sigmoid_out, float *tanh_out, int64_t n, void *stream);

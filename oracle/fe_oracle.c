@@ -670,7 +670,7 @@ void fo_policy_lstm(const double *obs, const float *whh, const float *wx, const 
             for (int u = 0; u < H; ++u) acc = fmaf(wout[u], h[u], acc);
             if (h_out) memcpy(h_out + ((size_t)n * A + a) * H, h, sizeof(float) * (size_t)H);
             if (out_act == 0) acc = fo_lstm_tanh(acc);
-            else acc = acc < -1.0f ? -1.0f : (acc > 1.0f ? 1.0f : acc);
+            else if (out_act == 1) acc = acc < -1.0f ? -1.0f : (acc > 1.0f ? 1.0f : acc);  /* 2: none (a critic's value) */
             actions_out[(size_t)n * A + a] = acc;
         }
     free(h); free(hn); free(c);

@@ -203,7 +203,8 @@ def lstm_pack(W_ih: np.ndarray, W_hh: np.ndarray, b_ih: np.ndarray, b_hh: np.nda
 
 def policy_lstm(obs: np.ndarray, whh: np.ndarray, wx: np.ndarray, wout: np.ndarray, bout: float, out_act: int = 0,
                 return_h: bool = False):
-    """Actions (N, A) f32 of the in-kernel LSTM policy on a materialised observation (N, W, 5A)."""
+    """Outputs (N, A) f32 of the in-kernel LSTM head on a materialised observation (N, W, 5A); out_act 0 tanh, 1 clamp to
+    [-1, 1], 2 none (a critic's value)."""
     obs = np.ascontiguousarray(obs, dtype=np.float64)
     N, W, c5 = obs.shape
     A = c5 // 5

@@ -419,3 +419,43 @@ def test_lstm_rollout_large_hidden_sizes_bit_for_bit(fe, fo, N, A, W, H, sample)
         assert_bits(t2n(env.cash), ref.cash, f"rep {rep} cash")
         assert_bits(t2n(roll.observation()), obs, f"rep {rep} observation()")
     assert len(seen) > 5, "the policy's outputs must vary across envs"
+
+
+@pytest.mark.parametrize("H,A", [(64, 1), (128, 3), (256, 1)])
+def test_lstm_forward_on_descriptors_is_the_critic_without_observations(fe, fo, H, A):
+    """fe_lstm_forward: the same head on ANY descriptors, env untouched -- here a critic (no output activation) valuing
+    all K + 1 states of a trajectory chunk in ONE launch.  Equal bit for bit to the oracle head on the rendered
+    observations, within 1e-5 relative of torch's nn.LSTM + nn.Linear, and the env's state does not move."""
+    from finenvs_amd.rollout import FusedLSTMRollout
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    N, W, K = 120, 4, 6
+    ref, env = _make(fe, fo, N, A, W, 6, 40, 0.05, False, seed=H + A)
+    actor = _modules(32, seed=1)
+    critic_lstm, critic_lin = _modules(H, seed=2, gain=3.0)
+    roll = FusedLSTMRollout.from_modules(env, *actor)
+    critic = FusedLSTMRollout.from_modules(env, critic_lstm, critic_lin, output_activation="none")
+    traj = TrajectoryBuffer(K, N, A, states=True)
+    roll.run(K, trajectory=traj)
+    state_before = [t.clone() for t in (env.cash, env.margin, env.env_indices, env.env_spots[:, 0])]
+    values = critic.forward(traj.obs_src, traj.obs_pos).reshape(K + 1, N, A)
+    for t_, b in zip((env.cash, env.margin, env.env_indices, env.env_spots[:, 0]), state_before):
+        assert torch.equal(t_, b), "forward() must not touch the env"
+    whh, wx, wout, bout = _packed(fo, critic_lstm, critic_lin)
+    for k in range(K + 1):
+        obs = traj.states(env, k)
+        want = fo.policy_lstm(t2n(obs), whh, wx, wout, bout, out_act=2)
+        assert_bits(t2n(values[k]), want, f"values of state {k}")
+        with torch.no_grad():
+            o32 = obs.float().cpu()
+            tv = torch.stack([critic_lin(critic_lstm(o32[:, :, 5 * a:5 * a + 5])[0][:, -1, :]).squeeze(1) for a in range(A)], 1)
+        torch.testing.assert_close(values[k].cpu(), tv, rtol=1e-5, atol=1e-5)  # tolerance: 1e-5
+    assert float(values.std()) > 1e-3  # the states differ and so do their values
+    # a gathered minibatch of descriptors, any size
+    idx = torch.randint(0, (K + 1) * N, (77,), device="cuda")
+    mb = critic.forward(traj.obs_src.reshape(-1)[idx], traj.obs_pos.reshape(-1, A)[idx])
+    assert torch.equal(mb, values.reshape(-1, A)[idx])
+    assert critic.forward(traj.obs_src[:0], traj.obs_pos[:0]).shape == (0, A)
+    from finenvs_amd._lib import FinEnvsNativeError
+    with pytest.raises(FinEnvsNativeError, match="out_activation"):
+        critic.run(1)  # an action needs bounds: "none" is for forward() only
