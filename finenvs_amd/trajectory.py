@@ -251,11 +251,12 @@ class TrajectoryBuffer:
         return ret, adv
 
     # ------------------------------------------------------------------ multi-GPU exchange
-    def all_gather(self, group=None, out: Optional[torch.Tensor] = None):
+    def all_gather(self, group=None, out: Optional[torch.Tensor] = None, with_states: bool = False):
         """One blocking collective: every rank receives every rank's packed chunk.
 
         Returns ``(actions (G, T, n, A), rewards (G, T, n), dones (G, T, n), packed)``
-        (all ranks must own the same n)."""
+        (all ranks must own the same n); ``with_states=True`` returns
+        ``(actions, rewards, dones, obs_src (G, T + 1, n), obs_pos (G, T + 1, n, A), packed)``."""
         import torch.distributed as dist
 
         G = dist.get_world_size(group)
@@ -263,6 +264,10 @@ class TrajectoryBuffer:
             out = torch.empty((G, self._nbytes), dtype=torch.uint8, device=self.device)
         dist.all_gather_into_tensor(out.view(-1), self._packed, group=group)
         a, r, d = self._typed(out, lead=(G,))
+        if with_states:
+            if not self.has_states:
+                raise RuntimeError("this TrajectoryBuffer was built without states=True")
+            return (a, r, d) + self._typed_states(out, lead=(G,)) + (out,)
         return a, r, d, out
 
     def all_gather_async(self, group=None) -> None:

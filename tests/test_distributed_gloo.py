@@ -154,6 +154,10 @@ def _states_worker(rank, world, port, q, N_TOTAL):
             ok &= torch.equal(buf.obs_src[0], s0) and torch.equal(buf.obs_pos[0], p0)
         joined = TrajectoryBuffer.join_shards(src_g, N_TOTAL)
         ok &= tuple(joined.shape) == (T + 1, N_TOTAL)
+        # the blocking form carries the states too (the chunk being filled: only its carried row 0 is set so far)
+        a_b, r_b, d_b, src_b, pos_b, packed_b = buf.all_gather(with_states=True)
+        ok &= tuple(src_b.shape) == (world, T + 1, CAP) and tuple(packed_b.shape) == (world, buf._nbytes)
+        ok &= torch.equal(src_b[rank, 0, :n], buf.obs_src[0])
         buf.drain()
         q.put((rank, bool(ok)))
     finally:
