@@ -359,7 +359,7 @@ __host__ __device__ inline size_t lstm_big_lds_bytes(int EB, int A, int H) {
 template <bool SINGLE, int RTW>
 __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(const Params p, const LstmArgs r) {
     constexpr int H = 64 * RTW, HP = H + 4, NG = H / 8, SP = 32;
-    constexpr int AHEAD = 4;  // k groups a weight fragment is loaded ahead of its MFMAs
+    constexpr int AHEAD = 4;  // k groups a weight fragment is loaded ahead of its MFMAs (8: no gain, spills at H = 512)
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
