@@ -30,6 +30,12 @@ constexpr int kBlock = 256;
 // everywhere (experiment builds).
 // "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their
 // -D set here and are only ever loaded by explicit path
+#ifndef FE_LSTM_BIG_RI   /* large-H LSTM kernel: row tiles per iteration / k groups of weights in flight (experiment builds vary them) */
+#define FE_LSTM_BIG_RI 4
+#endif
+#ifndef FE_LSTM_BIG_AHEAD
+#define FE_LSTM_BIG_AHEAD 2
+#endif
 #ifndef FE_XCD_BLOCKED   /* experiment builds only: XCD-blocked tile order in the step / reset kernels */
 #define FE_XCD_BLOCKED 0
 #endif

@@ -338,11 +338,12 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
 // ---- the same head for H = 256, 512, 1024 (the reference example trains hidden_dim = 1024): weights from L2 ----
 // Whh no longer fits a workgroup's registers (4 MiB / 16 MiB), so it is STREAMED: the host stores it fragment-major --
 // [row tile mt][k group g][lane][4], one contiguous KiB per (mt, g), exactly the A fragment of four MFMAs -- and every
-// wavefront loads its fragments with coalesced 16-byte loads two groups ahead of their use; the XCD's 4 MiB L2 (and the
+// wavefront loads its fragments with coalesced 16-byte loads two k groups (32 MFMAs) ahead of their use, continuously; the XCD's 4 MiB L2 (and the
 // Infinity Cache behind it) serves the 32 CUs that sweep the same matrix.  Per workgroup ONE 32-pair column tile
 // (H = 1024: h alone is 128 KiB of LDS, single-buffered: a wavefront keeps its new h values in registers until every
 // wavefront has finished reading the old ones -- two barriers per time step); each of the 8 wavefronts owns
-// RTW = H / 64 row tiles and runs them two at a time (two independent accumulator chains sharing the B fragment).
+// RTW = H / 64 row tiles and runs them four at a time (four independent accumulator chains sharing the B fragment;
+// measured against two: +6 % at H = 256, +2 % at H = 1024, tools/fused_bench.py with FUSED_LIB).
 // c_t and the pending h_t live in per-lane scratch (RTW x 4 floats each, touched once per row tile).  Same k order, same activations, same cell update as the register-
 // resident kernel: the same oracle function pins it bit for bit.
 __host__ __device__ inline size_t lstm_big_lds_bytes(int EB, int A, int H) {
@@ -359,7 +360,9 @@ __host__ __device__ inline size_t lstm_big_lds_bytes(int EB, int A, int H) {
 template <bool SINGLE, int RTW>
 __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(const Params p, const LstmArgs r) {
     constexpr int H = 64 * RTW, HP = H + 4, NG = H / 8, SP = 32;
-    constexpr int AHEAD = 4;  // k groups a weight fragment is loaded ahead of its MFMAs (8: no gain, spills at H = 512)
+    constexpr int RI = FE_LSTM_BIG_RI;  // row tiles run together: RI independent accumulator chains share every B fragment
+    constexpr int AHEAD = FE_LSTM_BIG_AHEAD;  // k groups a weight fragment is loaded ahead of its MFMAs
+    static_assert(RTW % RI == 0 && (H / 8) % AHEAD == 0, "row tiles / k groups must come in whole groups");
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
@@ -380,7 +383,7 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
     const int64_t NA = p.N * A;
     const int64_t rstride = 4 * (int64_t)A;
     const int mt0 = wave * RTW;  // this wavefront's row tiles: mt0 .. mt0 + RTW - 1
-    float4 wq[AHEAD][2];  // weight fragments in flight (see the k loop)
+    float4 wq[FE_LSTM_BIG_AHEAD][FE_LSTM_BIG_RI];  // weight fragments in flight (see the k loop)
     bool primed = false;
     for (int i = tid; i < H; i += kLstmBlock) s_wout[i] = r.wout[i];
 
@@ -421,67 +424,71 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
                 // a real loop over this wavefront's row-tile pairs: c_t and the pending h_t (RTW x 4 floats each per lane,
                 // touched once per 1040 MFMAs) are indexed dynamically, i.e. live in per-lane scratch, not in VGPRs
 #pragma unroll 1
-                for (int i0 = 0; i0 < RTW; i0 += 2) {
-                    f32x16 acc[2];
+                for (int i0 = 0; i0 < RTW; i0 += RI) {
+                    f32x16 acc[RI];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < RI; ++i)
 #pragma unroll
                         for (int rr = 0; rr < 16; ++rr) acc[i][rr] = 0.0f;
                     // input part: four MFMAs per row tile
-                    float4 wxv[2];
+                    float4 wxv[RI];
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < RI; ++i)
                         wxv[i] = *reinterpret_cast<const float4 *>(r.wx + ((size_t)32 * (mt0 + i0 + i) + col) * 8 + 4 * half);
 #pragma unroll
                     for (int m = 0; m < 4; ++m)
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) {
+                        for (int i = 0; i < RI; ++i) {
                             const float xs = m == 0 ? xc.x : (m == 1 ? xc.y : (m == 2 ? xc.z : xc.w));
                             const float ws = m == 0 ? wxv[i].x : (m == 1 ? wxv[i].y : (m == 2 ? wxv[i].z : wxv[i].w));
                             acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, acc[i], 0, 0, 0);
                         }
                     if (t > 0) {
                         // fragment-major weights: one coalesced KiB per (row tile, k group), AHEAD groups in flight -- across
-                        // row-tile pairs and time steps too: the tail of one k loop already fetches the head of the next
-                        // (the next pair's, or after the last pair the first pair's again: the matrix never changes)
+                        // row-tile groups and time steps too: the tail of one k loop already fetches the head of the next
+                        // (the next group's, or after the last group the first one's again: the matrix never changes)
                         const float4 *wbase = reinterpret_cast<const float4 *>(r.whh) + lane;
-                        const float4 *wf[2], *wfn[2];
+                        const float4 *wf[RI], *wfn[RI];
 #pragma unroll
-                        for (int i = 0; i < 2; ++i) {
+                        for (int i = 0; i < RI; ++i) {
                             wf[i] = wbase + ((size_t)(mt0 + i0 + i) * NG) * 64;
-                            wfn[i] = wbase + ((size_t)(mt0 + (i0 + 2 < RTW ? i0 + 2 : 0) + i) * NG) * 64;
+                            wfn[i] = wbase + ((size_t)(mt0 + (i0 + RI < RTW ? i0 + RI : 0) + i) * NG) * 64;
                         }
                         if (!primed) {
 #pragma unroll
                             for (int d = 0; d < AHEAD; ++d)
 #pragma unroll
-                                for (int i = 0; i < 2; ++i) wq[d][i] = wf[i][(size_t)d * 64];
+                                for (int i = 0; i < RI; ++i) wq[d][i] = wf[i][(size_t)d * 64];
                             primed = true;
                         }
-#pragma unroll 1  // a real loop: unrolled, its hoisted loads spill (NG is up to 128 groups of 8 MFMAs)
+#pragma unroll 1  // a real loop: unrolled, its hoisted loads spill (NG is up to 128 groups of 4 RI MFMAs)
                         for (int g0 = 0; g0 < NG; g0 += AHEAD) {
 #pragma unroll
                             for (int d = 0; d < AHEAD; ++d) {
                                 const int g = g0 + d;
-                                const float4 wv0 = wq[d][0], wv1 = wq[d][1];
+                                float4 wv[RI];
                                 const int gn = g + AHEAD;
-                                wq[d][0] = gn < NG ? wf[0][(size_t)gn * 64] : wfn[0][(size_t)(gn - NG) * 64];
-                                wq[d][1] = gn < NG ? wf[1][(size_t)gn * 64] : wfn[1][(size_t)(gn - NG) * 64];
+#pragma unroll
+                                for (int i = 0; i < RI; ++i) {
+                                    wv[i] = wq[d][i];
+                                    wq[d][i] = gn < NG ? wf[i][(size_t)gn * 64] : wfn[i][(size_t)(gn - NG) * 64];
+                                }
                                 const float4 hb = *reinterpret_cast<const float4 *>(hrow + 8 * g);
 #pragma unroll
                                 for (int m = 0; m < 4; ++m) {
                                     const float hs = m == 0 ? hb.x : (m == 1 ? hb.y : (m == 2 ? hb.z : hb.w));
-                                    const float w0 = m == 0 ? wv0.x : (m == 1 ? wv0.y : (m == 2 ? wv0.z : wv0.w));
-                                    const float w1 = m == 0 ? wv1.x : (m == 1 ? wv1.y : (m == 2 ? wv1.z : wv1.w));
-                                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(w0, hs, acc[0], 0, 0, 0);
-                                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(w1, hs, acc[1], 0, 0, 0);
+#pragma unroll
+                                    for (int i = 0; i < RI; ++i) {
+                                        const float ws = m == 0 ? wv[i].x : (m == 1 ? wv[i].y : (m == 2 ? wv[i].z : wv[i].w));
+                                        acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, hs, acc[i], 0, 0, 0);
+                                    }
                                 }
                             }
                         }
                     }
-                    // cell update, in-lane; the new h waits in registers until everyone has read the old one
+                    // cell update, in-lane; the new h waits (in scratch) until everyone has read the old one
 #pragma unroll
-                    for (int i = 0; i < 2; ++i) {
+                    for (int i = 0; i < RI; ++i) {
                         float og[4];
 #pragma unroll
                         for (int b = 0; b < 4; ++b) {

@@ -3,7 +3,7 @@ linear window form, linear table form, MLP head and LSTM head on the matrix core
 
     python tools/fused_bench.py <config> [form ...]      forms: window table mlp32 mlp64 mlp128 lstm32 lstm64 lstm128
     FUSED_W=4 overrides the config's window (the reference's LSTM scripts use num_intervals=4), FUSED_N the env count,
-    FUSED_K the steps per launch, FUSED_TILES a list of rollout tile overrides.
+    FUSED_K the steps per launch, FUSED_TILES a list of rollout tile overrides, FUSED_LIB the tag of an experiment build.
 """
 import os
 import sys
@@ -24,9 +24,14 @@ prices, day_id, _ = make_series(A)
 K = int(os.environ.get("FUSED_K", "32"))
 tiles = [int(x) for x in os.environ.get("FUSED_TILES", "0").split(",")]
 g = torch.Generator().manual_seed(0)
+native = None
+if os.environ.get("FUSED_LIB"):  # an experiment build (finenvs_amd.csrc.build.build_variant) by its tag
+    from finenvs_amd import _lib
+    native = _lib.load(os.path.join(os.path.dirname(_lib.LIB_PATH), "variants", f"libfinenvs_amd.{os.environ['FUSED_LIB']}.so"))
 for form in forms:
     for eb in tiles:
-        env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", obs_buffers=1)
+        env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", obs_buffers=1,
+                                        **({"_native": native} if native is not None else {}))
         if eb:
             env.set_launch(0, 0, eb)
         if form.startswith("torchlstm"):
