@@ -465,7 +465,9 @@ class TimeSeriesEnv:
         if rc != 0:
             _lib.check(rc)
         info: Dict = {}
-        if self.evaluate:
+        if self.evaluate and not getattr(self, "_defer_evaluation_check", False):
+            # (GraphedRollout defers this host read to the end of a K-step replay: the per-env bookkeeping already ran in
+            # the kernel, and steps past an env's termination cannot change its return, TSE:526-528)
             info = self.record_evaluation_metrics()
         elif self.redraw == "torch" and self._eval_env >= 0:
             # TSE:504-513: the eval env redraws a day from torch's global generator when it finishes

@@ -22,10 +22,12 @@ from .trajectory import TrajectoryBuffer
 class GraphedRollout:
     def __init__(self, env, policy: Callable[[torch.Tensor, int], torch.Tensor], num_steps: int,
                  trajectory: Optional[TrajectoryBuffer] = None, warmup: int = 2):
-        if env.evaluate:
-            raise ValueError("evaluate mode reads a device counter on the host every step; it cannot be captured")
-        if env.redraw != "device":
-            raise ValueError('GraphedRollout needs redraw="device" (redraw="torch" syncs on the eval env\'s done flag)')
+        if env.redraw != "device" and not env.evaluate:
+            raise ValueError('GraphedRollout needs redraw="device" (redraw="torch" syncs on the done flag of the eval env)')
+        # evaluate mode: the reference reads "have all envs terminated?" on the host every step (TSE:531); a captured
+        # replay cannot, so that read moves to the end of the K steps (self.info, evaluate_returns) -- the kernel keeps the
+        # per-env bookkeeping, and steps past an env's termination cannot change its return (TSE:526-528)
+        env._defer_evaluation_check = bool(env.evaluate)
         if env.obs_buffers < 1 or num_steps % env.obs_buffers != 0:
             raise ValueError("num_steps must be a multiple of env.obs_buffers (>= 1)")
         if trajectory is not None and trajectory.T != num_steps:
@@ -77,11 +79,27 @@ class GraphedRollout:
             self.rewards, self.dones = rews, dones
 
     def run(self) -> torch.Tensor:
-        """Replay the K captured steps; returns the newest observation (a static buffer)."""
+        """Replay the K captured steps; returns the newest observation (a static buffer).  In evaluate mode
+        ``self.info`` then holds ``{"returns": ...}`` if every env has finished its episode by now (TSE:523-536), else {}."""
         self.graph.replay()
         if self.traj is not None:
             self.traj.t = self.K
+        self.info = self.env.record_evaluation_metrics() if self.env.evaluate else {}
         return self.obs
+
+    def evaluate_returns(self, max_steps: int = 1_000_000) -> torch.Tensor:
+        """The reference's evaluation loop (examples/time_series/PPO_LSTM_testing_SPY.py:43-52) with ANY capturable
+        policy -- e.g. the torch ``nn.LSTM`` actor itself -- K steps per graph replay and one host read per replay
+        instead of one per step; returns the per-env episode returns."""
+        if not self.env.evaluate:
+            raise ValueError("evaluate_returns needs an env constructed with evaluate=True")
+        steps = 0
+        while steps < max_steps:
+            self.run()
+            steps += self.K
+            if "returns" in self.info:
+                return self.info["returns"]
+        raise RuntimeError("episodes did not all terminate within max_steps")
 
 
 class _FusedEvaluation:
@@ -284,7 +302,8 @@ class FusedLSTMRollout(_FusedEvaluation):
     Parameters are ``nn.LSTM``'s ``weight_ih_l0 (4H, 5)``, ``weight_hh_l0 (4H, H)``, ``bias_ih_l0``, ``bias_hh_l0``
     and the output layer's ``weight (1, H)`` / ``bias``; ``H`` in {32, 64, 128} (recurrent weights in registers) or
     {256, 512, 1024} (streamed from L2; the reference example trains ``hidden_dim=1024``).  The large sizes are a
-    throughput kernel (one 32-pair tile per workgroup walks the whole matrix): worthwhile from ~8k (env, asset) pairs up."""
+    throughput kernel (one 32-pair tile per workgroup walks the whole matrix): worthwhile from ~8k (env, asset) pairs up;
+    for an evaluation over a few hundred trading days use ``GraphedRollout(env, torch_actor, K).evaluate_returns()``."""
 
     OUTPUT_ACTIVATIONS = {"tanh": 0, "clamp": 1, "none": 2}  # "none": a critic (forward() only; an action needs bounds)
 

@@ -186,3 +186,38 @@ def test_graphed_rollout_keeps_states_as_descriptors(fe, fo):
             obs_e = obs_e.clone()
             assert torch.equal(traj.rewards[k], rew_e) and torch.equal(traj.dones[k], done_e) and torch.equal(traj.actions[k], ring[k])
         assert torch.equal(traj.states(graphed, K), obs_e), f"replay {rep} bootstrap state"
+
+
+def test_graphed_evaluation_loop_with_a_torch_lstm_actor(fe, fo):
+    """The reference's evaluation loop (PPO_LSTM_testing_SPY.py:43-52) with the torch nn.LSTM actor ITSELF as the
+    policy, K steps per hipGraph replay (evaluate mode: the "all terminated?" host read moves to the end of a replay):
+    the episode returns equal the eager step-by-step loop's, bit for bit."""
+    from finenvs_amd.data import synthetic
+    from finenvs_amd.rollout import GraphedRollout
+
+    N, W, H, K = 64, 4, 32, 8
+    prices, day_id, _ = synthetic.synthetic_series(7, 1, 40, 3, 0.05)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    torch.manual_seed(0)
+    lstm, lin = torch.nn.LSTM(5, H, batch_first=True).cuda(), torch.nn.Linear(H, 1).cuda()
+    with torch.no_grad():
+        lstm.weight_ih_l0.mul_(30.0)
+
+    @torch.no_grad()
+    def actor(states, k=0):
+        return torch.tanh(lin(lstm(states.float())[0][:, -1, :]))
+
+    mk = lambda: fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_buffers=2)
+    eager, graphed = mk(), mk()
+    states = eager.reset()
+    want = None
+    for _ in range(400):
+        states, _, _, info = eager.step(actor(states))
+        if "returns" in info:
+            want = info["returns"]
+            break
+    assert want is not None
+    roll = GraphedRollout(graphed, actor, K, warmup=0)
+    got = roll.evaluate_returns()
+    assert torch.equal(got, want)
+    assert float(got.abs().sum()) > 0
