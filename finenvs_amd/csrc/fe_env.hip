@@ -594,6 +594,10 @@ static int launch_lstm(fe_env *env, LstmArgs &r, int64_t count, const char *who,
     if (p.A > SP)
         return fail(FE_ERR_ARG, "%s: %d assets per env exceed the %d pairs of a workgroup tile (H = %d)", who, (int)p.A, SP, (int)H);
     int64_t eb = SP / p.A;
+    // few envs: a tile lives on one CU for a whole step, so spread them over the CUs -- halve the tile (down to one
+    // 32-pair column tile) while that fills otherwise idle CUs; a wavefront then runs fewer column tiles per time step
+    const int64_t min_eb = 32 / p.A > 1 ? 32 / p.A : 1;
+    while (!big && eb > min_eb && (p.N + eb - 1) / eb < env->cus) eb = eb / 2 > min_eb ? eb / 2 : min_eb;
     if (env->rollout_tile_override > 0 && env->rollout_tile_override < eb) eb = env->rollout_tile_override;
     p.EB = (int)eb;
     p.num_tiles = (p.N + eb - 1) / eb;

@@ -31,44 +31,57 @@ def mk():
     return finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, evaluate=True, obs_buffers=2)
 
 
-def timed(fn):
-    fn()
+def timed(make):
+    """`make()` builds env + rollout object once (not timed) and returns the loop; the loop runs one whole evaluation (until
+    every env has finished an episode) and returns its step count.  First evaluation warms up, the second is timed."""
+    loop = make()
+    loop()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    steps = fn()
+    steps = loop()
     torch.cuda.synchronize()
     return (time.perf_counter() - t0) / steps * 1e6
 
 
 def eager():
     env = mk()
-    states = env.reset()
-    for t in range(1, 5000):
-        states, _, _, info = env.step(actor(states))
-        if "returns" in info:
-            return t
+    box = [env.reset()]
+
+    def loop():
+        for t in range(1, 5000):
+            box[0], _, _, info = env.step(actor(box[0]))
+            if "returns" in info:
+                return t
+    return loop
 
 
 def graphed():
     env = mk()
     roll = GraphedRollout(env, actor, K)
-    steps = 0
-    while True:
-        roll.run()
-        steps += K
-        if "returns" in roll.info:
-            return steps
+
+    def loop():
+        steps = 0
+        while True:
+            roll.run()
+            steps += K
+            if "returns" in roll.info:
+                return steps
+    return loop
 
 
 def fused():
     env = mk()
     roll = FusedLSTMRollout.from_modules(env, lstm, lin)
-    steps = 0
-    while True:
-        roll.run(K, record_actions=False)
-        steps += K
-        if int(env._counters[0].item()) == env.num_envs:
-            return steps
+
+    def loop():
+        steps = 0
+        while True:
+            roll.run(K, record_actions=False)
+            steps += K
+            if int(env._counters[0].item()) == env.num_envs:
+                env.reset_evaluation_metrics()
+                return steps
+    return loop
 
 
 for name, fn in (("eager, one host read per step", eager), (f"hipGraph, {K} steps per replay", graphed), (f"fused kernel, {K} steps per launch", fused)):
