@@ -519,9 +519,13 @@ def fused_rollout_legs(args):
             ms = statistics.median(times)
             leg = {"form": form, "policy": policy, "envs": N, "num_assets": A, "window": W, "steps_per_launch": K,
                    "us_per_step": round(ms * 1e3, 2), "value": round(N / ms * 1e3, 1), "unit": "env-steps/s"}
-            if flop:
+            if flop:  # MFMA-bound legs: the contraction's FLOPs as executed against the dense f32 MFMA peak (256 CUs x 256 FLOP/cycle x 2.4 GHz)
                 leg["mfma_f32_tflops"] = round(flop / ms / 1e9, 1)
                 leg["mfma_f32_peak_tflops"] = 157.3
+                leg["roofline"] = {"bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
+                                   "frac": round(flop / ms / 1e9 / 157.3, 3), "traffic": None,
+                                   "note": "launch time from HIP events around K-step launches (policy + accounting); the f32-input MFMA "
+                                           "shares the vector ALUs with the activations (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r02g_lstm_summary.md)"}
             legs.append(leg)
             del env, roll
             torch.cuda.empty_cache()
