@@ -233,3 +233,38 @@ def test_single_asset_launch_geometry_rule(fe, fo):
         assert env.set_launch() == info  # 0 = automatic again
     small = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=64, num_envs=100, redraw="device")
     assert small.launch_info()["grid"] == (100 + small.launch_info()["tile_envs"] - 1) // small.launch_info()["tile_envs"]
+
+
+def test_two_envs_on_two_streams_do_not_interfere(fe, fo):
+    """The C ABI takes the stream per call and copies its parameter block per launch: two env objects stepped from two
+    HIP streams, interleaved without synchronisation in between, give exactly what each gives alone."""
+    from finenvs_amd.data import synthetic
+
+    prices, day_id, _ = synthetic.synthetic_series(6, 2, 60, 3, 0.05)
+    mk = lambda seed: fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=8, num_envs=5000, redraw="device", seed=seed)
+    g = torch.Generator(device="cuda").manual_seed(0)
+    acts = [(torch.rand((5000, 2), generator=g, device="cuda") * 2 - 1).float() for _ in range(12)]
+    alone = []
+    for seed in (1, 2):
+        env = mk(seed)
+        env.reset()
+        out = [env.step(a) for a in acts]
+        alone.append(([o[1].clone() for o in out], out[-1][0].clone(), env.cash.clone()))
+    envs, streams = [mk(1), mk(2)], [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    rews = [[], []]
+    last = [None, None]
+    for e, s in zip(envs, streams):
+        with torch.cuda.stream(s):
+            e.reset()
+    for a in acts:  # interleaved, no synchronisation between the two streams
+        for i, (e, s) in enumerate(zip(envs, streams)):
+            with torch.cuda.stream(s):
+                obs, r, d, _ = e.step(a)
+                rews[i].append(r)
+                last[i] = obs
+    torch.cuda.synchronize()
+    for i in range(2):
+        for k in range(len(acts)):
+            assert torch.equal(rews[i][k], alone[i][0][k]), f"env {i} step {k} rewards"
+        assert torch.equal(last[i], alone[i][1]) and torch.equal(envs[i].cash, alone[i][2])
