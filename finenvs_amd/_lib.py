@@ -54,6 +54,9 @@ SIGNATURES = {
     "fe_env_rollout_lstm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp,
                                       _vp, _vp, _vp, _vp]),
     "fe_lstm_activations": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "fe_lstm_split_workspace_floats": (_i64, [_i32, _i64]),
+    "fe_env_rollout_lstm_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp,
+                                            _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_lstm_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "fe_env_set_day": (C.c_int, [_vp, _i64, _i64, _vp]),
     "fe_env_launch_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),

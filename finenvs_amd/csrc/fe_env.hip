@@ -642,6 +642,77 @@ int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, 
     return launch_lstm(env, r, env->cfg.N, "fe_env_rollout_lstm", stream);
 }
 
+int64_t fe_lstm_split_workspace_floats(int32_t H, int64_t pairs) {
+    if (H < 8 || pairs < 1) return 0;
+    return 3 * ((pairs + 31) / 32) * (int64_t)H * 32;  // h (two buffers) + c, fragment-major: [column tile][H/8][64][4]
+}
+
+int fe_env_rollout_lstm_split(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout,
+                              float bout, int32_t H, int32_t out_activation, int32_t K, int64_t *obs_src, double *obs_pos,
+                              const float *noise, float std, float *actions_out, float *means_out, double *rewards_out,
+                              int32_t *dones_out, int64_t *states_src_out, double *states_pos_out, float *workspace,
+                              void *stream) {
+    if ((states_src_out == nullptr) != (states_pos_out == nullptr))
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm_split: states_src_out and states_pos_out go together");
+    if (noise && !(std >= 0.0f)) return fail(FE_ERR_ARG, "fe_env_rollout_lstm_split: std must be >= 0 when noise is given");
+    if (!env || !logret_f32 || !whh || !wx || !wout || !obs_src || !obs_pos || !rewards_out || !dones_out || !workspace || K < 1)
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm_split: bad argument");
+    if (H != 256 && H != 512 && H != 1024)
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm_split: H must be 256, 512 or 1024 (got %d)", (int)H);
+    if (out_activation < 0 || out_activation > 1)
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm_split: out_activation must be 0 (tanh) or 1 (clamp)");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_rollout_lstm_split: state not bound");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    Params p = env->p;
+    const int64_t NA = p.N * p.A, CT = (NA + 31) / 32;
+    // the accounting launch: few sleeves per workgroup, so that a handful of envs still spreads over the CUs
+    int64_t eb = 16 / p.A > 1 ? 16 / p.A : 1;  // (and their h_W rows, 4 H bytes per pair, are staged in LDS)
+    if (env->rollout_tile_override > 0 && env->rollout_tile_override < eb) eb = env->rollout_tile_override;
+    p.EB = (int)eb;
+    p.num_tiles = (p.N + eb - 1) / eb;
+    const size_t lds = ((table_rollout_lds_bytes(p.EB, p.A) + 15) & ~(size_t)15) + (size_t)p.EB * p.A * H * 4;
+    if (lds > 160 * 1024)
+        return fail(FE_ERR_ARG, "fe_env_rollout_lstm_split: %d sleeves per env x H = %d do not fit the LDS of the accounting launch", (int)p.A, (int)H);
+    {
+        const void *fk = p.A == 1 ? (const void *)fe_lstm_split_finish_kernel<true> : (const void *)fe_lstm_split_finish_kernel<false>;
+        hipError_t ha = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ha != hipSuccess) return hip_fail(ha, "fe_env_rollout_lstm_split: hipFuncSetAttribute");
+    }
+    const int64_t fgrid = p.num_tiles < 8 * 256 ? p.num_tiles : 8 * 256;
+    const bool single = p.A == 1;
+    LstmSplitArgs s;
+    s.a.lr32 = logret_f32; s.a.whh = whh; s.a.wx = wx; s.a.wout = wout; s.a.bout = bout; s.a.H = H; s.a.out_act = out_activation;
+    s.a.K = 1; s.a.obs_src = obs_src; s.a.obs_pos = obs_pos; s.a.std = std; s.a.traj_src = states_src_out; s.a.traj_pos = states_pos_out;
+    s.a.forward_only = 0;
+    s.hbuf = workspace; s.cbuf = workspace + 2 * CT * (int64_t)H * 32; s.pairs = NA;
+    const dim3 ggrid((unsigned)(H / 8), (unsigned)((CT + kBlock / 64 - 1) / (kBlock / 64)));
+    const size_t glds = (size_t)(H / 8) * 64 * 16;  // one gate-row tile of weights: H / 8 KiB (128 KiB at H = 1024)
+    {
+        const void *gk = single ? (const void *)fe_lstm_split_gates_kernel<true> : (const void *)fe_lstm_split_gates_kernel<false>;
+        hipError_t ha = hipFuncSetAttribute(gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+        if (ha != hipSuccess) return hip_fail(ha, "fe_env_rollout_lstm_split: hipFuncSetAttribute");
+    }
+    for (int k = 0; k < K; ++k) {
+        s.k = k;
+        s.a.noise = noise ? noise + (int64_t)k * NA : nullptr;
+        s.a.actions_out = actions_out ? actions_out + (int64_t)k * NA : nullptr;
+        s.a.means_out = means_out ? means_out + (int64_t)k * NA : nullptr;
+        s.a.rew_out = rewards_out + (int64_t)k * p.N;
+        s.a.done_out = dones_out + (int64_t)k * p.N;
+        for (int t = 0; t < p.W; ++t) {
+            s.t = t;
+            if (single) hipLaunchKernelGGL(fe_lstm_split_gates_kernel<true>, ggrid, dim3(kBlock), glds, (hipStream_t)stream, p, s);
+            else hipLaunchKernelGGL(fe_lstm_split_gates_kernel<false>, ggrid, dim3(kBlock), glds, (hipStream_t)stream, p, s);
+        }
+        if (single) hipLaunchKernelGGL(fe_lstm_split_finish_kernel<true>, dim3((unsigned)fgrid), dim3(kBlock), lds, (hipStream_t)stream, p, s);
+        else hipLaunchKernelGGL(fe_lstm_split_finish_kernel<false>, dim3((unsigned)fgrid), dim3(kBlock), lds, (hipStream_t)stream, p, s);
+    }
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm_split launch");
+    return FE_OK;
+}
+
 int fe_lstm_forward(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout, float bout,
                     int32_t H, int32_t out_activation, const int64_t *obs_src, const double *obs_pos, int64_t count,
                     float *out, void *stream) {

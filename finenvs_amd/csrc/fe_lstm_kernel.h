@@ -552,4 +552,207 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
     }
 }
 
+// ---- large H at SMALL env counts: one launch per time step, the row tiles spread over the whole GPU ----
+// The fused kernels keep a tile on one CU for a whole env step; at H = 1024 that CU walks 128 row tiles (1.8 ms per step
+// however few envs there are).  Below a few thousand pairs the step is better cut the other way: one launch per LSTM
+// time step in which workgroup (mt, y) computes gate-row tile mt for four 32-pair column tiles (one per wavefront), with
+// h_{t-1}, h_t and c_t in global memory -- FRAGMENT-MAJOR, [column tile][k group][lane][4]: the float4 a lane of row
+// tile mt produces (units 8 mt + 4 half + b of its pair) IS the B fragment of k group g = mt of the next time step, so
+// both sides are one coalesced KiB per wavefront -- and the launch boundary is the exchange of h.  A last launch per env
+// step reduces h_W to the action and runs the accounting (one lane per sleeve).  Same k order, same activations, same
+// cell update: the same oracle function, bit for bit.  The floor is the accumulator chain itself: H/2 + 4 DEPENDENT MFMAs
+// per time step, and a dependent v_mfma_f32_32x32x2_f32 issues only every ~150 cycles when nothing else runs on the SIMD
+// (measured: 35 us per time step at H = 1024 whatever the prefetch depth; rocprofv3 kernel trace).
+struct LstmSplitArgs {
+    LstmArgs a;          // weights (whh fragment-major), descriptors, outputs of step k (pointers already offset)
+    float *hbuf;         // [2][CT][H/8][64][4] f32: h, double-buffered by time-step parity
+    float *cbuf;         // [CT][H/8][64][4] f32
+    int32_t t;           // time step of this launch (gates kernel)
+    int32_t k;           // env step of this launch (finish kernel: row k + 1 of the trajectory)
+    int64_t pairs;       // N * A
+};
+
+template <bool SINGLE>
+__global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Params p, const LstmSplitArgs s) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LstmArgs &r = s.a;
+    const int A = SINGLE ? 1 : p.A;
+    const int H = r.H, NG = H / 8, t = s.t;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int col = lane & 31, half = lane >> 5;
+    const int mt = blockIdx.x;
+    const int64_t ct = (int64_t)blockIdx.y * (kBlock / 64) + wave;
+    const int64_t CT = (s.pairs + 31) / 32;
+    // Every launch starts with a cold L2, so this row tile's weights (H/8 KiB, fragment-major) come from the Infinity Cache
+    // or HBM at ~1.5 us latency: the whole workgroup fetches them ONCE into LDS with 16 loads per lane in flight (tens of
+    // KiB per workgroup), instead of each wavefront trickling them in a few KiB ahead of its accumulator chain.
+    float4 *s_w = reinterpret_cast<float4 *>(smem);  // [NG][64]
+    if (t > 0) {
+        const float4 *wsrc = reinterpret_cast<const float4 *>(r.whh) + ((size_t)mt * NG) * 64;
+        const int total = NG * 64;
+        for (int base = 0; base < total; base += 16 * kBlock) {
+            float4 v[16];
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int idx = base + j * kBlock + tid;
+                v[j] = wsrc[idx < total ? idx : total - 1];
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int idx = base + j * kBlock + tid;
+                if (idx < total) s_w[idx] = v[j];
+            }
+        }
+    }
+    __syncthreads();
+    if (ct >= CT) return;  // (no further barriers)
+    const int64_t q = ct * 32 + col;
+    const int64_t qc = q < s.pairs ? q : s.pairs - 1;
+    const int64_t n = SINGLE ? qc : qc / A;
+    const int aa = SINGLE ? 0 : (int)(qc - n * A);
+    // B fragment of the input part: the row's four log-returns | position, 1, 0, 0
+    float4 xv;
+    if (half == 0) xv = *reinterpret_cast<const float4 *>(r.lr32 + r.obs_src[n] + 4 * aa + (int64_t)t * 4 * A);
+    else xv = make_float4((float)r.obs_pos[qc], 1.0f, 0.0f, 0.0f);
+    const float4 wxv = *reinterpret_cast<const float4 *>(r.wx + ((size_t)32 * mt + col) * 8 + 4 * half);
+    f32x16 acc;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) acc[rr] = 0.0f;
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+        const float xs = m == 0 ? xv.x : (m == 1 ? xv.y : (m == 2 ? xv.z : xv.w));
+        const float ws = m == 0 ? wxv.x : (m == 1 ? wxv.y : (m == 2 ? wxv.z : wxv.w));
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, acc, 0, 0, 0);
+    }
+    const size_t frag = (size_t)CT * NG * 64;  // float4s per h buffer
+    float4 *hnext = reinterpret_cast<float4 *>(s.hbuf) + (size_t)(t & 1) * frag;
+    if (t > 0) {
+        const float4 *hprev = reinterpret_cast<const float4 *>(s.hbuf) + (size_t)((t + 1) & 1) * frag + ((size_t)ct * NG) * 64 + lane;
+        constexpr int AHEAD = FE_LSTM_SPLIT_AHEAD;  // k groups of h in flight (h was written by the previous launch: also cold)
+        float4 hq[AHEAD];
+#pragma unroll
+        for (int d = 0; d < AHEAD; ++d) hq[d] = hprev[(size_t)d * 64];
+#pragma unroll 1
+        for (int g0 = 0; g0 < NG; g0 += AHEAD) {
+#pragma unroll
+            for (int d = 0; d < AHEAD; ++d) {
+                const float4 hb = hq[d];
+                const int gn = g0 + d + AHEAD < NG ? g0 + d + AHEAD : NG - 1;  // (the last loads are redundant, in range)
+                hq[d] = hprev[(size_t)gn * 64];
+                const float4 wv = s_w[(g0 + d) * 64 + lane];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    const float hs = m == 0 ? hb.x : (m == 1 ? hb.y : (m == 2 ? hb.z : hb.w));
+                    const float ws = m == 0 ? wv.x : (m == 1 ? wv.y : (m == 2 ? wv.z : wv.w));
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, hs, acc, 0, 0, 0);
+                }
+            }
+        }
+    }
+    // cell update, in-lane: acc[4b + gate] belongs to unit 8 mt + 4 half + b of pair col
+    float4 *cptr = reinterpret_cast<float4 *>(s.cbuf) + ((size_t)ct * NG + mt) * 64 + lane;
+    const float4 cold = t > 0 ? *cptr : make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+    const float co[4] = {cold.x, cold.y, cold.z, cold.w};
+    float cn[4], og[4], hv[4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+        const v2f sif = lstm_act2<false, false>((v2f){acc[4 * b + 0], acc[4 * b + 1]});
+        const v2f tgo = lstm_act2<true, false>((v2f){acc[4 * b + 2], acc[4 * b + 3]});
+        const float t1 = sif.y * co[b];
+        const float t2 = sif.x * tgo.x;
+        cn[b] = t1 + t2;
+        og[b] = tgo.y;
+    }
+#pragma unroll
+    for (int b = 0; b < 4; b += 2) {
+        const v2f tc = lstm_act2<true, true>((v2f){cn[b], cn[b + 1]});
+        hv[b] = og[b] * tc.x;
+        hv[b + 1] = og[b + 1] * tc.y;
+    }
+    *cptr = make_float4(cn[0], cn[1], cn[2], cn[3]);
+    hnext[((size_t)ct * NG + mt) * 64 + lane] = make_float4(hv[0], hv[1], hv[2], hv[3]);
+}
+
+// output layer + accounting of one env step (the tail of fe_rollout_lstm_kernel's step loop as its own launch)
+template <bool SINGLE>
+__global__ __launch_bounds__(kBlock) void fe_lstm_split_finish_kernel(const Params p, const LstmSplitArgs s) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const LstmArgs &r = s.a;
+    const int A = SINGLE ? 1 : p.A;
+    const int EB = p.EB;
+    const int S = EB * A;
+    const int H = r.H, NG = H / 8;
+    const TileLds l = carve_lds(smem, EB, S);
+    size_t off = (size_t)EB * 8 + (size_t)S * 8 + (size_t)S * 8 + (size_t)S * 4 + (size_t)S * 4 + (size_t)EB * 4;
+    off = (off + 7) & ~(size_t)7;
+    int64_t *l_idx = reinterpret_cast<int64_t *>(smem + off);
+    off = (off + (size_t)EB * 8 + 15) & ~(size_t)15;
+    float4 *s_hq = reinterpret_cast<float4 *>(smem + off);  // [EB * A][2 NG]
+    const int tid = threadIdx.x;
+    const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
+    const int a = SINGLE ? 0 : tid - e * A;
+    const int64_t NA = p.N * A;
+    const int64_t CT = (s.pairs + 31) / 32;
+    const float *hW = s.hbuf + (size_t)((p.W - 1) & 1) * CT * NG * 64 * 4;
+    for (int64_t tile = blockIdx.x; tile < p.num_tiles; tile += gridDim.x) {
+        const int64_t n0 = tile * EB;
+        const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+        const bool active = e < ebt;
+        const int64_t n = n0 + e;
+        const int64_t sl = n * A + a;
+        SleeveReg st = rollout_load_state(p, active && !r.forward_only, n, sl);
+        // h_W of the tile's pairs -> LDS, the whole workgroup loading (the launch starts with a cold L2: a lane walking its
+        // own 4 KiB alone would pay ~0.3 us per dependent-latency step): [pair][2 NG] float4, units ascending per pair
+        {
+            const int tp = ebt * A;  // pairs of this tile: sl0 .. sl0 + tp - 1
+            const int64_t sl0 = n0 * A;
+            const int per = 2 * NG;  // float4s per pair
+            for (int i = tid; i < tp * per; i += kBlock) {
+                const int pq = i / per, j = i - pq * per;       // pair, (g, half) = (j >> 1, j & 1)
+                const int64_t qg = sl0 + pq;
+                s_hq[i] = reinterpret_cast<const float4 *>(hW)[(((size_t)(qg >> 5) * NG + (j >> 1)) * 64 + (qg & 31) + 32 * (j & 1))];
+            }
+            __syncthreads();
+        }
+        float act = 0.0f;
+        if (active) {
+            if (s.k == 0 && r.traj_src) {  // row 0: the state the first policy evaluation saw
+                r.traj_pos[sl] = r.obs_pos[sl];
+                if (a == 0) r.traj_src[n] = r.obs_src[n];
+            }
+            const float4 *hp = s_hq + (size_t)(e * A + a) * (2 * NG);  // this pair's h_W, units ascending (staged above)
+            float o = r.bout;
+#pragma unroll 4
+            for (int g = 0; g < NG; ++g) {  // units 8g + 4 half + c
+                const float4 h0 = hp[2 * g], h1 = hp[2 * g + 1];
+                const float *w = r.wout + 8 * g;
+                o = fmaf(w[0], h0.x, o); o = fmaf(w[1], h0.y, o); o = fmaf(w[2], h0.z, o); o = fmaf(w[3], h0.w, o);
+                o = fmaf(w[4], h1.x, o); o = fmaf(w[5], h1.y, o); o = fmaf(w[6], h1.z, o); o = fmaf(w[7], h1.w, o);
+            }
+            act = r.out_act == 0 ? lstm_tanh(o) : (r.out_act == 2 ? o : (o < -1.0f ? -1.0f : (o > 1.0f ? 1.0f : o)));
+            if (r.means_out) r.means_out[sl] = act;
+            if (r.noise && n != p.eval_env) {
+                const float dev = r.std * r.noise[sl];
+                const float smp = act + dev;
+                act = smp < -1.0f ? -1.0f : (smp > 1.0f ? 1.0f : smp);
+            }
+            if (r.actions_out) r.actions_out[sl] = act;
+        }
+        if (!r.forward_only) {  // (uniform)
+            account_keep<SINGLE>(p, l, l_idx, A, e, a, active, n, st, act, r.rew_out, r.done_out);
+            rollout_store_state(p, active, a, n, sl, st);
+            if (active) {
+                r.obs_pos[sl] = l.pos[e * A + a];
+                if (a == 0) r.obs_src[n] = l.src[e];
+                if (r.traj_src) {
+                    r.traj_pos[(int64_t)(s.k + 1) * NA + sl] = l.pos[e * A + a];
+                    if (a == 0) r.traj_src[(int64_t)(s.k + 1) * p.N + n] = l.src[e];
+                }
+            }
+        }
+        __syncthreads();  // s_hq and the accounting scratch are reused by the next tile
+    }
+}
+
 }  // namespace

@@ -302,10 +302,14 @@ class FusedLSTMRollout(_FusedEvaluation):
     Parameters are ``nn.LSTM``'s ``weight_ih_l0 (4H, 5)``, ``weight_hh_l0 (4H, H)``, ``bias_ih_l0``, ``bias_hh_l0``
     and the output layer's ``weight (1, H)`` / ``bias``; ``H`` in {32, 64, 128} (recurrent weights in registers) or
     {256, 512, 1024} (streamed from L2; the reference example trains ``hidden_dim=1024``).  The large sizes are a
-    throughput kernel (one 32-pair tile per workgroup walks the whole matrix): worthwhile from ~8k (env, asset) pairs up;
-    for an evaluation over a few hundred trading days use ``GraphedRollout(env, torch_actor, K).evaluate_returns()``."""
+    throughput kernel (one 32-pair tile per workgroup walks the whole matrix); below ``SPLIT_BELOW_PAIRS`` (env, asset)
+    pairs -- an evaluation over a few hundred trading days -- ``run`` issues one launch per LSTM time step instead."""
 
     OUTPUT_ACTIVATIONS = {"tanh": 0, "clamp": 1, "none": 2}  # "none": a critic (forward() only; an action needs bounds)
+    # H >= 256 below this many (env, asset) pairs: one launch per LSTM time step with the gate-row tiles spread over the
+    # whole GPU (fe_env_rollout_lstm_split) instead of one tile per CU for a whole step; ``self.split`` = True / False
+    # overrides the choice (measured cross-over: profiles/r02_microbench/lstm_split.txt)
+    SPLIT_BELOW_PAIRS = 4096
 
     def __init__(self, env, weight_ih: torch.Tensor, weight_hh: torch.Tensor, bias_ih: torch.Tensor, bias_hh: torch.Tensor,
                  weight_out: torch.Tensor, bias_out: float = 0.0, output_activation: str = "tanh"):
@@ -321,6 +325,7 @@ class FusedLSTMRollout(_FusedEvaluation):
         if env.redraw != "device" and not env.evaluate:
             raise ValueError('the fused rollout needs redraw="device" (or evaluate mode): no host in the loop')
         self.env, self.H, self.out_act = env, H, self.OUTPUT_ACTIVATIONS[output_activation]
+        self.split, self._workspace = None, None
         dev = env._dev
         self.obs_src = torch.empty((env.num_envs,), dtype=torch.int64, device=dev)
         self.obs_pos = torch.empty((env.num_envs, env.num_assets), dtype=torch.float64, device=dev)
@@ -415,13 +420,22 @@ class FusedLSTMRollout(_FusedEvaluation):
                 raise ValueError(f"noise must be ({K}, {N}, {A}) float32 on {dev}")
             noise = noise.contiguous()
         self.means = torch.empty((K, N, A), dtype=torch.float32, device=dev) if record_means else None
-        _lib.check(env._lib.fe_env_rollout_lstm(
-            env._handle, self._lr32.data_ptr(), self.whh.data_ptr(), self.wx.data_ptr(), self.wout.data_ptr(), self.bout,
-            self.H, self.out_act, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
-            noise.data_ptr() if noise is not None else None, float(std) if noise is not None else 0.0,
-            actions.data_ptr() if actions is not None else None, self.means.data_ptr() if record_means else None,
-            rewards.data_ptr(), dones.data_ptr(), src_out.data_ptr() if src_out is not None else None,
-            pos_out.data_ptr() if pos_out is not None else None, env._stream()))
+        args = (env._handle, self._lr32.data_ptr(), self.whh.data_ptr(), self.wx.data_ptr(), self.wout.data_ptr(), self.bout,
+                self.H, self.out_act, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
+                noise.data_ptr() if noise is not None else None, float(std) if noise is not None else 0.0,
+                actions.data_ptr() if actions is not None else None, self.means.data_ptr() if record_means else None,
+                rewards.data_ptr(), dones.data_ptr(), src_out.data_ptr() if src_out is not None else None,
+                pos_out.data_ptr() if pos_out is not None else None)
+        use_split = self.split if self.split is not None else (self.H > 128 and N * A < self.SPLIT_BELOW_PAIRS)
+        if use_split:
+            if self.H <= 128:
+                raise ValueError("split=True is for H in {256, 512, 1024}")
+            if self._workspace is None:
+                n = int(env._lib.fe_lstm_split_workspace_floats(self.H, N * A))
+                self._workspace = torch.empty((n,), dtype=torch.float32, device=dev)
+            _lib.check(env._lib.fe_env_rollout_lstm_split(*args, self._workspace.data_ptr(), env._stream()))
+        else:
+            _lib.check(env._lib.fe_env_rollout_lstm(*args, env._stream()))
         if trajectory is not None:
             trajectory.mark_filled(K)
         return actions, rewards, dones

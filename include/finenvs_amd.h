@@ -250,6 +250,22 @@ int fe_env_rollout_lstm(fe_env *env, const float *logret_f32, const float *whh, 
                         int32_t *dones_out, int64_t *states_src_out, double *states_pos_out, void *stream);
 
 /*
+ * fe_env_rollout_lstm for H in {256, 512, 1024} at SMALL env counts (the reference's own evaluation runs one env per
+ * trading day with hidden_dim = 1024, examples/time_series/PPO_LSTM_testing_SPY.py:27-29, 41): instead of keeping a tile
+ * on one CU for a whole step, every LSTM time step is ONE launch whose workgroups are the 4H/32 gate-row tiles (x groups
+ * of four 32-pair column tiles); h and c live in `workspace` (fe_lstm_split_workspace_floats(H, N*A) floats, fragment-
+ * major) and the launch boundary is the exchange of h; a last launch per env step reduces h_W and runs the accounting.
+ * W + 1 launches per env step, all on `stream` (capturable in a hipGraph).  Arguments, weights layout (whh fragment-major),
+ * semantics and results exactly as fe_env_rollout_lstm: the same oracle function pins both bit for bit.
+ */
+int64_t fe_lstm_split_workspace_floats(int32_t H, int64_t pairs);
+int fe_env_rollout_lstm_split(fe_env *env, const float *logret_f32, const float *whh, const float *wx, const float *wout,
+                              float bout, int32_t H, int32_t out_activation, int32_t K, int64_t *obs_src, double *obs_pos,
+                              const float *noise, float std, float *actions_out, float *means_out, double *rewards_out,
+                              int32_t *dones_out, int64_t *states_src_out, double *states_pos_out, float *workspace,
+                              void *stream);
+
+/*
  * The same LSTM head (same weights layout, same arithmetic) evaluated on ANY `count` observation descriptors without
  * stepping an env and without materialising the observations: out (count*A) f32.  out_activation 2 = none -- a critic
  * (finenvs/agents/PPO/critic.py, CriticLSTM: LSTMNetwork with the Identity output) -- so the values of all K + 1

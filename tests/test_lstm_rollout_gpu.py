@@ -459,3 +459,61 @@ def test_lstm_forward_on_descriptors_is_the_critic_without_observations(fe, fo, 
     from finenvs_amd._lib import FinEnvsNativeError
     with pytest.raises(FinEnvsNativeError, match="out_activation"):
         critic.run(1)  # an action needs bounds: "none" is for forward() only
+
+
+@pytest.mark.parametrize("N,A,W,H,sample,evaluate", [
+    (9, 1, 4, 1024, False, True),     # the reference's own evaluation: one env per trading day of SPY dummy, hidden_dim 1024
+    (70, 1, 4, 256, True, False),     # three column tiles (one partial), sampled actions, training mode
+    (21, 3, 3, 512, False, False),    # sleeves: pairs = 63
+    (150, 1, 1, 256, False, False),   # W = 1: a single gate launch per step; more column tiles than one workgroup row
+])
+def test_lstm_split_path_equals_oracle_and_fused_path(fe, fo, N, A, W, H, sample, evaluate):
+    """fe_env_rollout_lstm_split (one launch per LSTM time step, gate-row tiles over the whole GPU, h / c in global
+    memory): the same arithmetic as the fused kernel -- bit for bit against the oracle loop, trajectory rows included."""
+    from finenvs_amd.rollout import FusedLSTMRollout
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    ref, env = _make(fe, fo, N, A, W, 6, 30, 0.05, evaluate, seed=N + H)
+    lstm, lin = _modules(H, seed=H + 1, gain=2.0)
+    whh, wx, wout, bout = _packed(fo, lstm, lin)
+    roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    assert roll.split is None and N * A < roll.SPLIT_BELOW_PAIRS  # the automatic choice takes the split path here
+    obs = ref.reset().copy()
+    g = torch.Generator(device="cuda").manual_seed(3)
+    std = np.float32(0.5)
+    for rep in range(3):
+        K = 4
+        traj = TrajectoryBuffer(K, N, A, states=True)
+        noise = torch.randn((K, N, A), generator=g, device="cuda") if sample else None
+        acts, rews, dones = roll.run(K, noise=noise, std=float(std) if sample else None, trajectory=traj, record_means=True)
+        assert roll._workspace is not None
+        for k in range(K):
+            assert_bits(t2n(traj.states(env, k)), obs, f"rep {rep} stored state {k}")
+            mean = fo.policy_lstm(obs, whh, wx, wout, bout)
+            assert_bits(t2n(roll.means[k]), mean, f"rep {rep} step {k} means")
+            a_ref = mean
+            if sample:
+                a_ref = np.clip((mean + (std * t2n(noise[k])).astype(np.float32)).astype(np.float32), np.float32(-1), np.float32(1))
+                if not evaluate:
+                    a_ref[N - 1] = mean[N - 1]
+            obs, r_ref, d_ref, _ = ref.step(a_ref)
+            obs = obs.copy()
+            what = f"H={H} rep {rep} step {k}"
+            assert_bits(t2n(acts[k]), a_ref, what + " actions")
+            assert_bits(t2n(rews[k]), r_ref, what + " rewards")
+            assert_bits(t2n(dones[k]), d_ref, what + " dones")
+        assert_bits(t2n(traj.states(env, K)), obs, f"rep {rep} bootstrap state")
+        assert_bits(t2n(env.cash), ref.cash, f"rep {rep} cash")
+        assert_bits(t2n(env.env_indices), ref.env_idx, f"rep {rep} env_idx")
+        if evaluate and int(ref.n_terminated[0]) == N:
+            env.reset_evaluation_metrics()
+            ref.terminated[:] = 0; ref.episode_returns[:] = 0; ref.n_terminated[0] = 0
+    # the fused kernel, forced, continues the same trajectory identically
+    roll.split = False
+    acts, rews, dones = roll.run(2)
+    for k in range(2):
+        a_ref = fo.policy_lstm(obs, whh, wx, wout, bout)
+        obs, r_ref, d_ref, _ = ref.step(a_ref)
+        obs = obs.copy()
+        assert_bits(t2n(acts[k]), a_ref, f"fused continuation step {k} actions")
+        assert_bits(t2n(rews[k]), r_ref, f"fused continuation step {k} rewards")

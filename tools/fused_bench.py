@@ -68,6 +68,8 @@ for form in forms:
             with torch.no_grad():
                 lstm.weight_ih_l0[:, :4].mul_(6.0 * H ** 0.5)
             roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+            if os.environ.get("FUSED_SPLIT"):  # 1 / 0: force the per-time-step (split) or the fused large-H path
+                roll.split = os.environ["FUSED_SPLIT"] == "1"
             flop = 2.0 * N * A * 4 * H * (8 * W + H * (W - 1))  # gate contractions as executed, per step
         elif form.startswith("mlp"):
             H = int(form[3:])
