@@ -392,6 +392,7 @@ def test_lstm_rollout_large_hidden_sizes_bit_for_bit(fe, fo, N, A, W, H, sample)
     lstm, lin = _modules(H, seed=H, gain=2.0)
     whh, wx, wout, bout = _packed(fo, lstm, lin)
     roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    roll.split = False  # THIS test pins the fused large-H kernel (so few pairs would otherwise take the per-time-step path)
     # the device copy is fragment-major: [row tile][k group][lane][4] of the same packed rows
     frag = whh.reshape(4 * H // 32, 32, H // 8, 2, 4).transpose(0, 2, 3, 1, 4).reshape(4 * H, H)
     assert_bits(t2n(roll.whh), np.ascontiguousarray(frag), "fragment-major Whh")

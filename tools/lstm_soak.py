@@ -39,10 +39,12 @@ for c in range(cases):
     lstm, lin = _modules(H, seed=int(rng.integers(1, 1000)), gain=6.0 if H <= 128 else 2.0)
     whh, wx, wout, bout = _packed(fo, lstm, lin)
     roll = FusedLSTMRollout.from_modules(env, lstm, lin)
+    if H > 128:
+        roll.split = bool(rng.integers(0, 2))  # the per-time-step path or the fused large-H kernel
     obs = ref.reset().copy()
     g = torch.Generator(device="cuda").manual_seed(c)
     std = np.float32(0.4)
-    what = f"case {c} H={H} A={A} W={W} N={N} eval={evaluate} sample={sample} traj={use_traj}"
+    what = f"case {c} H={H} A={A} W={W} N={N} eval={evaluate} sample={sample} traj={use_traj} split={roll.split}"
     for rep in range(3):
         K = int(rng.integers(1, 6))
         traj = TrajectoryBuffer(K, N, A, states=True) if use_traj else None
