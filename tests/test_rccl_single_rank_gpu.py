@@ -31,7 +31,6 @@ traj = TrajectoryBuffer(T, N, A, states=True)
 g = torch.Generator(device="cuda").manual_seed(1)
 obs = env.reset()
 traj.begin(env)
-kept = []
 for chunk in range(3):
     seen = []
     for t in range(T):
@@ -41,9 +40,6 @@ for chunk in range(3):
         obs, *_ = env.step(a, rewards_out=r, dones_out=d, descriptors_out=traj.state_slot())
     want = (traj.actions.clone(), traj.rewards.clone(), traj.dones.clone(), traj.obs_src.clone(), traj.obs_pos.clone())
     traj.all_gather_async()          # RCCL, on its own stream; the next chunk fills meanwhile
-    kept.append((want, seen))
-    if chunk:
-        pass
     got = traj.wait_gathered(with_states=True)
     for name, w, gt in zip(("actions", "rewards", "dones", "obs_src", "obs_pos"), want, got):
         assert gt.shape[0] == 1 and torch.equal(gt[0], w), name
