@@ -36,8 +36,11 @@ constexpr int kBlock = 256;
 #ifndef FE_LSTM_BIG_AHEAD
 #define FE_LSTM_BIG_AHEAD 2
 #endif
+#ifndef FE_LSTM_BIG_PIN
+#define FE_LSTM_BIG_PIN 0
+#endif
 #ifndef FE_LSTM_SPLIT_AHEAD
-#define FE_LSTM_SPLIT_AHEAD 8
+#define FE_LSTM_SPLIT_AHEAD 16
 #endif
 #ifndef FE_XCD_BLOCKED   /* experiment builds only: XCD-blocked tile order in the step / reset kernels */
 #define FE_XCD_BLOCKED 0

@@ -473,6 +473,9 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
                                     wv[i] = wq[d][i];
                                     wq[d][i] = gn < NG ? wf[i][(size_t)gn * 64] : wfn[i][(size_t)(gn - NG) * 64];
                                 }
+#if FE_LSTM_BIG_PIN
+                                __builtin_amdgcn_sched_barrier(0);  // keep the refill loads AHEAD groups before their use
+#endif
                                 const float4 hb = *reinterpret_cast<const float4 *>(hrow + 8 * g);
 #pragma unroll
                                 for (int m = 0; m < 4; ++m) {
@@ -633,6 +636,8 @@ __global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Param
         float4 hq[AHEAD];
 #pragma unroll
         for (int d = 0; d < AHEAD; ++d) hq[d] = hprev[(size_t)d * 64];
+        float4 wnext = s_w[lane];  // the A fragment is read from LDS one k group ahead of its MFMAs (a dependent MFMA can
+                                   // issue every 64 cycles, tools/mfma_probe.hip: nothing may wait in between)
 #pragma unroll 1
         for (int g0 = 0; g0 < NG; g0 += AHEAD) {
 #pragma unroll
@@ -640,7 +645,11 @@ __global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Param
                 const float4 hb = hq[d];
                 const int gn = g0 + d + AHEAD < NG ? g0 + d + AHEAD : NG - 1;  // (the last loads are redundant, in range)
                 hq[d] = hprev[(size_t)gn * 64];
-                const float4 wv = s_w[(g0 + d) * 64 + lane];
+                const float4 wv = wnext;
+                wnext = s_w[(g0 + d + 1 < NG ? g0 + d + 1 : NG - 1) * 64 + lane];
+                // keep the refill load HERE, AHEAD groups before its use: left alone, the scheduler sinks it to ~3 groups ahead
+                // (and splits it into dword loads), which the cold h cannot cover
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
                     const float hs = m == 0 ? hb.x : (m == 1 ? hb.y : (m == 2 ? hb.z : hb.w));

@@ -309,7 +309,7 @@ class FusedLSTMRollout(_FusedEvaluation):
     # H >= 256 below this many (env, asset) pairs: one launch per LSTM time step with the gate-row tiles spread over the
     # whole GPU (fe_env_rollout_lstm_split) instead of one tile per CU for a whole step; ``self.split`` = True / False
     # overrides the choice (measured cross-over: profiles/r02_microbench/lstm_split.txt)
-    SPLIT_BELOW_PAIRS = 4096
+    SPLIT_BELOW_PAIRS = 5120
 
     def __init__(self, env, weight_ih: torch.Tensor, weight_hh: torch.Tensor, bias_ih: torch.Tensor, bias_hh: torch.Tensor,
                  weight_out: torch.Tensor, bias_out: float = 0.0, output_activation: str = "tanh"):
