@@ -371,6 +371,9 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
     load_head(p, ps.act2, ps.n_nn, ps.idx2, ps.spot2);
     if constexpr (kActionsTwoAhead<OT>)
         if (ps.act2) ps.action_nn = p.actions[ps.n_nn];
+#if FE_STEP_PIN
+    __builtin_amdgcn_sched_barrier(0);  // experiment: keep the prefetch loads issued BEFORE phase 2 (the scheduler may sink them)
+#endif
     stream_tile<OT, VEC, true>(p, l, stage, 1, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave,
                                kBlock / 64, FIRST && kHoistFirst<OT>, pre);
     tile_barrier();  // LDS is reused by the next tile
