@@ -497,6 +497,9 @@ __device__ __forceinline__ void mlp_policy_block(const Params &p, const MlpArgs 
     for (int c = 0; c < nchunks; ++c) {
 #pragma unroll
         for (int i = 0; i < CH; ++i) xn[i] = load_x((c + 1) * CH + i);
+        // keep the next chunk's row loads ahead of this chunk's MFMAs: left alone the scheduler sinks them towards their use,
+        // which costs 6 - 7 % at H = 128 (neutral at H = 32 / 64; tools/fused_bench.py with FUSED_LIB=mlppin)
+        if constexpr (NT == 4 || FE_MLP_PIN) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             float4 wa[NT];
