@@ -36,6 +36,9 @@ constexpr int kBlock = 256;
 #ifndef FE_LSTM_BIG_AHEAD
 #define FE_LSTM_BIG_AHEAD 2
 #endif
+#ifndef FE_LSTM_PIN
+#define FE_LSTM_PIN 0
+#endif
 #ifndef FE_MLP_PIN
 #define FE_MLP_PIN 0
 #endif

@@ -223,6 +223,9 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
 #pragma unroll
                 for (int j = 0; j < MAXNT; ++j)
                     xn[j] = half == 0 ? *reinterpret_cast<const float4 *>(xsrc[j] + (int64_t)tn * rstride) : xh[j];
+                // keep the next time step's row loads up here (the scheduler otherwise sinks them towards their use): -6.5 % at
+                // H = 128, -1 % at 64, +1.5 % at 32 (tools/fused_bench.py with FUSED_LIB=lstmpin)
+                if constexpr (NT >= 2 || FE_LSTM_PIN) __builtin_amdgcn_sched_barrier(0);
                 // JB column tiles at a time: with MPW row tiles that is MPW * JB >= 2 independent accumulator chains,
                 // so a dependent MFMA never waits for its predecessor's 16 passes
 #pragma unroll
