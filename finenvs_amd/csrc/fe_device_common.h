@@ -36,6 +36,9 @@ constexpr int kBlock = 256;
 #ifndef FE_LSTM_BIG_AHEAD
 #define FE_LSTM_BIG_AHEAD 2
 #endif
+#ifndef FE_HOIST_ALL   /* single-asset f64 step kernel: every tile's table tuples are loaded one tile ahead */
+#define FE_HOIST_ALL 0
+#endif
 #ifndef FE_LSTM_PIN
 #define FE_LSTM_PIN 0
 #endif
@@ -337,6 +340,7 @@ __host__ __device__ inline size_t lds_bytes(int EB, int A) {
     size_t S = (size_t)EB * A;
     size_t b = 4 * (size_t)kStageBytes + (size_t)EB * 8 + S * 8;
     if (A > 1) b += S * 8 + S * 4 + S * 4 + (size_t)EB * 4;
+    else b += (size_t)EB * 8;  // window descriptors of the next tile (kHoistAll)
 #if FE_STEP_VARIANT == 1
     if (A == 1) b = 4 * (size_t)kStageBytes + 4 * ((size_t)EB * 16);  // descriptors of four tiles at once
 #elif FE_STEP_VARIANT == 2

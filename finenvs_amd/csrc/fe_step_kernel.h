@@ -353,11 +353,27 @@ constexpr bool kActionsTwoAhead = sizeof(OT) == 8;
 // One tile of the single-asset pipeline: account it (inputs already in registers), prefetch the next tile's body and
 // the head of the one after, stream its observation.  FIRST: the workgroup's first tile, whose first phase-2
 // iteration may use table tuples loaded before the accounting (`pre`).
+// kHoistAll (experiment builds, FE_HOIST_ALL=1; measured 5 % SLOWER at config 2, profiles/r02_microbench/ab_xcd_blocked.txt:
+// the other workgroups of the CU already hide a tile's table latency): EVERY tile's table tuples are loaded one tile ahead -- the next tile's window descriptors
+// need only its head (idx, spot), which arrived during the previous phase 2, so they are published (src_next) under the
+// barrier the accounting needs anyway, and each wavefront issues the next tile's table loads before it streams the
+// current tile; single_tile returns them for the next call.
+template <typename OT>
+constexpr bool kHoistAll = kHoistFirst<OT> && FE_HOIST_ALL;
+
 template <typename OT, int VEC, bool FIRST>
-__device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, OT *stage, PipeState &ps, int64_t tile,
-                                            int64_t k, int EB, int e, int lane, int wave, PreTuples<OT> pre) {
+__device__ __forceinline__ PreTuples<OT> single_tile(const Params &p, const TileLds &l, int64_t *src_next, OT *stage,
+                                                     PipeState &ps, int64_t tile, int64_t k, int EB, int e, int lane,
+                                                     int wave, PreTuples<OT> pre) {
     const int64_t n0 = tile * EB;
     const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
+    if constexpr (kHoistAll<OT>) {
+        if (ps.act1) {  // (memory safety only, as in account_core: a well-formed state has s0 + W <= L)
+            const int64_t s0 = ps.spot1 + 1;
+            const int64_t s0c = s0 + p.W <= p.L ? s0 : p.L - p.W;
+            src_next[e] = (ps.idx1 * p.L + s0c) * 4;  // A == 1
+        }
+    }
     account_core<true>(p, l, 1, e, 0, ps.act0, ps.n_cur, ps.n_cur, ps.in_cur, ps.action_cur, p.rew, p.done);
     tile_barrier();
 #if FE_STAMP
@@ -374,8 +390,28 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
 #if FE_STEP_PIN
     __builtin_amdgcn_sched_barrier(0);  // experiment: keep the prefetch loads issued BEFORE phase 2 (the scheduler may sink them)
 #endif
+    PreTuples<OT> pre_next{};
+    if constexpr (kHoistAll<OT>) {
+        const int64_t tn = tile_at(p, k + 1);
+        if (tn < p.num_tiles) {
+            const int64_t leftn = p.N - tn * EB;
+            const uint32_t tuplesn = (uint32_t)(leftn < (int64_t)EB ? leftn : (int64_t)EB) * (uint32_t)p.W;
+            if ((uint32_t)wave * kTuplesPerIter<OT> < tuplesn) {
+                TileLds ln = l;
+                ln.src = src_next;
+                TupleOf<OT> vn[kTuplesPerIter<OT> / 64];
+                stream_load<OT, true>(p, ln, 1, tuplesn, (uint32_t)wave * kTuplesPerIter<OT>, lane, vn);
+                pre_next.v0 = vn[0];
+                pre_next.v1 = vn[1];
+                if constexpr (kTuplesPerIter<OT> / 64 == 4) {
+                    pre_next.v2 = vn[2];
+                    pre_next.v3 = vn[3];
+                }
+            }
+        }
+    }
     stream_tile<OT, VEC, true>(p, l, stage, 1, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave,
-                               kBlock / 64, FIRST && kHoistFirst<OT>, pre);
+                               kBlock / 64, (FIRST && kHoistFirst<OT>) || (kHoistAll<OT> && !FIRST), pre);
     tile_barrier();  // LDS is reused by the next tile
     ps.in_cur = ps.in_nxt;
     ps.action_cur = ps.action_nxt;
@@ -383,6 +419,7 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
     ps.n_cur = ps.n_nxt; ps.act0 = ps.act1;
     ps.n_nxt = ps.n_nn; ps.act1 = ps.act2;
     ps.idx1 = ps.idx2; ps.spot1 = ps.spot2;
+    return pre_next;
 }
 
 // Wavefronts per SIMD the kernels are built for = workgroups per CU they are launched with (configure_launch): the
@@ -402,6 +439,9 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
     const TileLds l = carve_lds(smem + 4 * kStageBytes, EB, EB * A);
+    // single asset: window descriptors of the NEXT tile (kHoistAll), behind src[EB] and pos[EB]
+    int64_t *src_next = reinterpret_cast<int64_t *>(smem + 4 * kStageBytes) + 2 * EB;
+    (void)src_next;
     const int tid = threadIdx.x;
     const int e = SINGLE ? tid : (int)fdiv((uint32_t)tid, p.div_A);
     const int a = SINGLE ? 0 : tid - e * A;
@@ -559,7 +599,7 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
         load_head(p, ps.act1, ps.n_nxt, ps.idx1, ps.spot1);
         // one tile per call; the workgroup's first tile is peeled (FIRST) so that `pre` dies before the loop
         if (tile < p.num_tiles) {
-            single_tile<OT, VEC, true>(p, l, stage, ps, tile, k, EB, e, lane, wave, pre);
+            PreTuples<OT> carried = single_tile<OT, VEC, true>(p, l, src_next, stage, ps, tile, k, EB, e, lane, wave, pre);
 #if FE_STAMP
             if (stamps && tid == 0) {
                 stamps[blockIdx.x * 8 + 1] = ps.t_accounted;
@@ -567,7 +607,7 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, SINGLE, RESET_ONLY>)) 
             }
 #endif
             for (k = 1; (tile = tile_at(p, k)) < p.num_tiles; ++k)
-                single_tile<OT, VEC, false>(p, l, stage, ps, tile, k, EB, e, lane, wave, PreTuples<OT>{});
+                carried = single_tile<OT, VEC, false>(p, l, src_next, stage, ps, tile, k, EB, e, lane, wave, carried);
         }
 #if FE_STAMP
         if (stamps && tid == 0) {
