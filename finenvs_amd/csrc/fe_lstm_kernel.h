@@ -567,8 +567,8 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
 // both sides are one coalesced KiB per wavefront -- and the launch boundary is the exchange of h.  A last launch per env
 // step reduces h_W to the action and runs the accounting (one lane per sleeve).  Same k order, same activations, same
 // cell update: the same oracle function, bit for bit.  The floor is the accumulator chain itself: H/2 + 4 DEPENDENT MFMAs
-// per time step, and a dependent v_mfma_f32_32x32x2_f32 issues only every ~150 cycles when nothing else runs on the SIMD
-// (measured: 35 us per time step at H = 1024 whatever the prefetch depth; rocprofv3 kernel trace).
+// per time step at 64 cycles each (tools/mfma_probe.hip) = 15 us at H = 1024; the launch reaches 25 - 30 us: its L2 is
+// cold, so the row tile's weights are staged through LDS by the whole workgroup and h arrives 16 k groups ahead.
 struct LstmSplitArgs {
     LstmArgs a;          // weights (whh fragment-major), descriptors, outputs of step k (pointers already offset)
     float *hbuf;         // [2][CT][H/8][64][4] f32: h, double-buffered by time-step parity
