@@ -578,6 +578,16 @@ struct LstmSplitArgs {
     int64_t pairs;       // N * A
 };
 
+// PER float4s per lane, all loads in flight before the first LDS write
+template <int PER>
+__device__ __forceinline__ void lstm_stage_weights(const float4 *src, float4 *dst, int tid) {
+    float4 v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) v[j] = src[j * kBlock + tid];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) dst[j * kBlock + tid] = v[j];
+}
+
 template <bool SINGLE>
 __global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Params p, const LstmSplitArgs s) {
     extern __shared__ __align__(16) unsigned char smem[];
@@ -590,30 +600,13 @@ __global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Param
     const int mt = blockIdx.x;
     const int64_t ct = (int64_t)blockIdx.y * (kBlock / 64) + wave;
     const int64_t CT = (s.pairs + 31) / 32;
-    // Every launch starts with a cold L2, so this row tile's weights (H/8 KiB, fragment-major) come from the Infinity Cache
-    // or HBM at ~1.5 us latency: the whole workgroup fetches them ONCE into LDS with 16 loads per lane in flight (tens of
-    // KiB per workgroup), instead of each wavefront trickling them in a few KiB ahead of its accumulator chain.
-    float4 *s_w = reinterpret_cast<float4 *>(smem);  // [NG][64]
-    if (t > 0) {
-        const float4 *wsrc = reinterpret_cast<const float4 *>(r.whh) + ((size_t)mt * NG) * 64;
-        const int total = NG * 64;
-        for (int base = 0; base < total; base += 16 * kBlock) {
-            float4 v[16];
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int idx = base + j * kBlock + tid;
-                v[j] = wsrc[idx < total ? idx : total - 1];
-            }
-#pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int idx = base + j * kBlock + tid;
-                if (idx < total) s_w[idx] = v[j];
-            }
-        }
-    }
-    __syncthreads();
-    if (ct >= CT) return;  // (no further barriers)
-    const int64_t q = ct * 32 + col;
+    // Every launch starts with a cold L2: everything this wavefront needs first goes out FIRST -- its row of x, the input
+    // weights, the first AHEAD k groups of h -- and then the whole workgroup fetches the row tile's recurrent weights (H/8
+    // KiB, fragment-major; Infinity Cache / HBM at ~1.5 us) ONCE into LDS with all its loads in flight together (up to 32 per
+    // lane), instead of each wavefront trickling them in a few KiB ahead of its accumulator chain.
+    const bool valid = ct < CT;
+    const int64_t ctc = valid ? ct : CT - 1;
+    const int64_t q = ctc * 32 + col;
     const int64_t qc = q < s.pairs ? q : s.pairs - 1;
     const int64_t n = SINGLE ? qc : qc / A;
     const int aa = SINGLE ? 0 : (int)(qc - n * A);
@@ -622,6 +615,25 @@ __global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Param
     if (half == 0) xv = *reinterpret_cast<const float4 *>(r.lr32 + r.obs_src[n] + 4 * aa + (int64_t)t * 4 * A);
     else xv = make_float4((float)r.obs_pos[qc], 1.0f, 0.0f, 0.0f);
     const float4 wxv = *reinterpret_cast<const float4 *>(r.wx + ((size_t)32 * mt + col) * 8 + 4 * half);
+    const size_t frag = (size_t)CT * NG * 64;  // float4s per h buffer
+    float4 *hnext = reinterpret_cast<float4 *>(s.hbuf) + (size_t)(t & 1) * frag;
+    const float4 *hprev = reinterpret_cast<const float4 *>(s.hbuf) + (size_t)((t + 1) & 1) * frag + ((size_t)ctc * NG) * 64 + lane;
+    constexpr int AHEAD = FE_LSTM_SPLIT_AHEAD;  // k groups of h in flight (h was written by the previous launch: also cold)
+    float4 hq[AHEAD];
+    if (t > 0) {
+#pragma unroll
+        for (int d = 0; d < AHEAD; ++d) hq[d] = hprev[(size_t)d * 64];
+    }
+    float4 *s_w = reinterpret_cast<float4 *>(smem);  // [NG][64]
+    if (t > 0) {
+        const float4 *wsrc = reinterpret_cast<const float4 *>(r.whh) + ((size_t)mt * NG) * 64;
+        const int per = NG * 64 / kBlock;  // float4s per lane: 8 (H = 256), 16, 32 (H = 1024)
+        if (per == 32) lstm_stage_weights<32>(wsrc, s_w, tid);
+        else if (per == 16) lstm_stage_weights<16>(wsrc, s_w, tid);
+        else lstm_stage_weights<8>(wsrc, s_w, tid);
+    }
+    __syncthreads();
+    if (!valid) return;  // (no further barriers)
     f32x16 acc;
 #pragma unroll
     for (int rr = 0; rr < 16; ++rr) acc[rr] = 0.0f;
@@ -631,14 +643,7 @@ __global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Param
         const float ws = m == 0 ? wxv.x : (m == 1 ? wxv.y : (m == 2 ? wxv.z : wxv.w));
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ws, xs, acc, 0, 0, 0);
     }
-    const size_t frag = (size_t)CT * NG * 64;  // float4s per h buffer
-    float4 *hnext = reinterpret_cast<float4 *>(s.hbuf) + (size_t)(t & 1) * frag;
     if (t > 0) {
-        const float4 *hprev = reinterpret_cast<const float4 *>(s.hbuf) + (size_t)((t + 1) & 1) * frag + ((size_t)ct * NG) * 64 + lane;
-        constexpr int AHEAD = FE_LSTM_SPLIT_AHEAD;  // k groups of h in flight (h was written by the previous launch: also cold)
-        float4 hq[AHEAD];
-#pragma unroll
-        for (int d = 0; d < AHEAD; ++d) hq[d] = hprev[(size_t)d * 64];
         float4 wnext = s_w[lane];  // the A fragment is read from LDS one k group ahead of its MFMAs (a dependent MFMA can
                                    // issue every 64 cycles, tools/mfma_probe.hip: nothing may wait in between)
 #pragma unroll 1
