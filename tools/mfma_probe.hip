@@ -23,6 +23,7 @@ __global__ void k_latency(float a, float b, float *out, long long *cycles, int n
     f32x4 acc16;
     for (int i = 0; i < 16; ++i) acc32[i] = 0.0f;
     for (int i = 0; i < 4; ++i) acc16[i] = 0.0f;
+    const long long w0 = wall_clock64();
     const long long t0 = clock64();
     for (int i = 0; i < n; ++i) {
         if (KIND == 0) acc32 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc32, 0, 0, 0);
@@ -30,7 +31,11 @@ __global__ void k_latency(float a, float b, float *out, long long *cycles, int n
     }
     const long long t1 = clock64();
     out[threadIdx.x] = KIND == 0 ? acc32[0] : acc16[0];
-    if (threadIdx.x == 0) cycles[0] = t1 - t0;
+    const long long w1 = wall_clock64();
+    if (threadIdx.x == 0) {
+        cycles[0] = t1 - t0;
+        cycles[1] = w1 - w0;  // 100 MHz
+    }
 }
 
 int main() {
@@ -61,15 +66,16 @@ int main() {
     }
     printf("v_mfma_f32_16x16x4_f32 over 200 random 16x16 tiles (51200 outputs): mismatches vs fmaf chain k=0..3: %d, vs k=3..0: %d, vs one f64 sum: %d\n",
            mismatch_seq, mismatch_rev, mismatch_pair);
-    float *dout; long long *dcy, hcy;
-    hipMalloc(&dout, 256); hipMalloc(&dcy, 8);
+    float *dout; long long *dcy, hcy[2];
+    hipMalloc(&dout, 256); hipMalloc(&dcy, 16);
     for (int kind = 0; kind < 2; ++kind)
-        for (int n : {256, 1024}) {
+        for (int n : {256, 1024, 16384}) {
             if (kind == 0) hipLaunchKernelGGL(k_latency<0>, dim3(1), dim3(64), 0, 0, 1.0f, 0.5f, dout, dcy, n);
             else hipLaunchKernelGGL(k_latency<1>, dim3(1), dim3(64), 0, 0, 1.0f, 0.5f, dout, dcy, n);
-            hipMemcpy(&hcy, dcy, 8, hipMemcpyDeviceToHost);
-            printf("%s: %d dependent MFMAs on one wavefront: %lld clock64 ticks = %.1f per MFMA\n",
-                   kind == 0 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", n, hcy, (double)hcy / n);
+            hipMemcpy(hcy, dcy, 16, hipMemcpyDeviceToHost);
+            printf("%s: %d dependent MFMAs on one wavefront: %lld clock64 ticks = %.1f per MFMA; %.2f us wall -> %.0f ns per MFMA (clock64 runs at %.0f MHz)\n",
+                   kind == 0 ? "v_mfma_f32_32x32x2_f32" : "v_mfma_f32_16x16x4_f32", n, hcy[0], (double)hcy[0] / n, hcy[1] / 100.0,
+                   hcy[1] * 10.0 / n, hcy[0] / (hcy[1] / 100.0));
         }
     return 0;
 }
