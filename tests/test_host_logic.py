@@ -186,3 +186,35 @@ def test_trajectory_state_descriptor_protocol_on_host_tensors():
         with pytest.raises(RuntimeError, match="states=True"):
             fn()
     assert plain._nbytes == N * (8 * T + 4 * A * T + 4 * T)  # the compact layout is unchanged without states
+
+
+def test_lstm_weight_packing_host_side_matches_the_oracle_packing():
+    """finenvs_amd.rollout.lstm_row_order (torch, product) and oracle.fe_oracle.lstm_row_order / lstm_pack (numpy, test
+    side) are written independently: same row permutation, same packed Wx (bias = one f32 add), and the fragment-major
+    layout of the streaming kernels is a pure re-arrangement of the packed rows."""
+    import numpy as np
+    import torch
+
+    from finenvs_amd.rollout import lstm_row_order
+    from oracle import fe_oracle as fo
+
+    rng = np.random.default_rng(0)
+    for H in (32, 128, 256):
+        order = lstm_row_order(H).numpy()
+        assert np.array_equal(order, fo.lstm_row_order(H))
+        w_ih = rng.normal(size=(4 * H, 5)).astype(np.float32)
+        w_hh = rng.normal(size=(4 * H, H)).astype(np.float32)
+        b_ih, b_hh = rng.normal(size=4 * H).astype(np.float32), rng.normal(size=4 * H).astype(np.float32)
+        whh, wx = fo.lstm_pack(w_ih, w_hh, b_ih, b_hh)
+        # what FusedLSTMRollout.set_weights builds (without touching a GPU)
+        t_hh, t_ih = torch.from_numpy(w_hh), torch.from_numpy(w_ih)
+        bias = torch.from_numpy(b_ih) + torch.from_numpy(b_hh)
+        t_wx = torch.zeros((4 * H, 8), dtype=torch.float32)
+        t_wx[:, :5] = t_ih[lstm_row_order(H)]
+        t_wx[:, 5] = bias[lstm_row_order(H)]
+        assert np.array_equal(t_wx.numpy(), wx) and np.array_equal(t_hh[lstm_row_order(H)].numpy(), whh)
+        frag = t_hh[lstm_row_order(H)].reshape(4 * H // 32, 32, H // 8, 2, 4).permute(0, 2, 3, 1, 4).contiguous().reshape(-1)
+        # element ((mt * NG + g) * 64 + lane) * 4 + c  ==  packed[32 mt + (lane & 31)][8 g + 4 (lane >> 5) + c]
+        NG = H // 8
+        for mt, g, lane, c in ((0, 0, 0, 0), (1, 2, 37, 3), (4 * H // 32 - 1, NG - 1, 63, 1), (3, 1, 31, 2)):
+            assert frag[((mt * NG + g) * 64 + lane) * 4 + c] == whh[32 * mt + (lane & 31), 8 * g + 4 * (lane >> 5) + c]
