@@ -44,5 +44,5 @@ $OUT/csv_asan $OUT/ok.csv $OUT/nonl.csv $OUT/trunc.csv $OUT/garbage.csv $OUT/emp
 # the oracle under ASan/UBSan: replay the golden suite against the instrumented library
 cd $ROOT
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) FE_ORACLE_LIB=$OUT/libfe_oracle.so \
-    python3 -m pytest tests/test_oracle_golden.py -q -x -p no:cacheprovider 2>&1 | tail -3
+    python3 -m pytest tests/test_oracle_golden.py tests/test_oracle_lstm.py -q -x -p no:cacheprovider 2>&1 | tail -3
 echo "sanitizer pass done"
