@@ -621,10 +621,14 @@ def main():
             "extra_configs": [{k: v for k, v in e.items() if k != "cpu_baseline"} for e in extras],
             "fused_rollouts": fused,
         }
-        print(json.dumps(out), file=result_out, flush=True)
+    else:
+        out = None
     if D.dist is not None:
         D.barrier()
         D.dist.destroy_process_group()
+    if out is not None:  # the very last thing this process writes: nothing (process-group teardown chatter) follows it
+        sys.stderr.flush()
+        print(json.dumps(out), file=result_out, flush=True)
 
 
 if __name__ == "__main__":
