@@ -27,7 +27,6 @@ class GraphedRollout:
         # evaluate mode: the reference reads "have all envs terminated?" on the host every step (TSE:531); a captured
         # replay cannot, so that read moves to the end of the K steps (self.info, evaluate_returns) -- the kernel keeps the
         # per-env bookkeeping, and steps past an env's termination cannot change its return (TSE:526-528)
-        env._defer_evaluation_check = bool(env.evaluate)
         if env.obs_buffers < 1 or num_steps % env.obs_buffers != 0:
             raise ValueError("num_steps must be a multiple of env.obs_buffers (>= 1)")
         if trajectory is not None and trajectory.T != num_steps:
@@ -58,6 +57,15 @@ class GraphedRollout:
 
     def _iterate(self, record: bool) -> None:
         env, traj = self.env, self.traj
+        # the host read of evaluate mode is deferred only while THESE steps are issued (warm-up / capture); the env object
+        # behaves as usual for anyone stepping it directly afterwards
+        env._defer_evaluation_check = bool(env.evaluate)
+        try:
+            self._iterate_steps(env, traj, record)
+        finally:
+            env._defer_evaluation_check = False
+
+    def _iterate_steps(self, env, traj, record: bool) -> None:
         if traj is not None:
             if traj.has_states:  # unconditionally, so that the captured graph contains it whatever t was at capture time
                 traj._carry_state(traj._cur, traj._cur)
