@@ -135,6 +135,32 @@ def pmc_traffic(config: int, f32: bool):
 
 
 _LIVE_PMC_BROKEN = []  # first failure of a live counter pass: later workloads fall back to the committed figures
+_PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_", "ROCTX_")
+
+
+def under_profiler(environ=None) -> bool:
+    """True when THIS process already runs under rocprofv3 / a rocprofiler tool library.  A nested
+    `rocprofv3 --pmc` would inherit the preloaded tool library: it initialises the GPU in the child launcher, which
+    then exec()s the application -- the exec-after-GPU-init case this pool's boxes do not survive."""
+    env = os.environ if environ is None else environ
+    if env.get("ROCP_TOOL_LIBRARIES") or env.get("HSA_TOOLS_LIB") or env.get("ROCPROFILER_LIBRARY_CTOR"):
+        return True
+    return "rocprof" in env.get("LD_PRELOAD", "").lower()
+
+
+def pmc_child_env(environ=None) -> dict:
+    """Environment for the counter-pass children: the parent's, minus everything a profiler may have put there."""
+    env = dict(os.environ if environ is None else environ)
+    for k in list(env):
+        if k.startswith(_PROFILER_ENV_PREFIXES):
+            del env[k]
+    pre = [x for x in env.get("LD_PRELOAD", "").replace(":", " ").split() if "rocprof" not in x.lower()]
+    if pre:
+        env["LD_PRELOAD"] = ":".join(pre)
+    else:
+        env.pop("LD_PRELOAD", None)
+    env["TMPDIR"] = "/tmp"
+    return env
 
 
 def live_pmc_traffic(config: int, f32: bool, redraw: str, no_audition: bool = False):
@@ -150,6 +176,9 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str, no_audition: bool = Fa
 
     if _LIVE_PMC_BROKEN:
         return None, _LIVE_PMC_BROKEN[0]
+    if under_profiler():
+        _LIVE_PMC_BROKEN.append("already under a profiler (no nested rocprofv3)")
+        return None, _LIVE_PMC_BROKEN[0]
     exe = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(exe):
         _LIVE_PMC_BROKEN.append("rocprofv3 not found")
@@ -164,7 +193,7 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str, no_audition: bool = Fa
                 cmd.append("--obs-f32")
             if no_audition:
                 cmd.append("--no-audition")
-            r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL,
+            r = subprocess.run(cmd, cwd="/tmp", env=pmc_child_env(), stdout=subprocess.DEVNULL,
                                stderr=subprocess.DEVNULL, timeout=90)
             if r.returncode != 0:
                 _LIVE_PMC_BROKEN.append(f"rocprofv3 --pmc {kind} child exited with {r.returncode}")

@@ -13,7 +13,7 @@ current stream.  There is no CPU path.
 Keyword-only extensions: ``num_envs`` (env n -> day n mod D), ``num_assets`` /
 ``prices`` / ``day_id`` (tensor input, multi-asset "sleeve" contract of
 DESIGN.md), ``tables`` (ready-made (D,L,4A) price/log-return tables),
-``obs_dtype``, ``obs_buffers`` (opt-in ring of env-owned observation buffers), ``obs_audition`` (ring mode:
+``obs_dtype``, ``cast_actions`` (accept non-f32 actions by casting; default: ValueError), ``obs_buffers`` (opt-in ring of env-owned observation buffers), ``obs_audition`` (ring mode:
 extra candidate buffers to try at construction, the fastest stay), ``redraw``, ``seed``, ``env_indices``, ``rank`` /
 ``world_size`` (contiguous env shards, one process per GPU).
 """
@@ -66,6 +66,7 @@ class TimeSeriesEnv:
         obs_buffers: int = 0,
         obs_audition: int = 0,
         redraw: str = "torch",
+        cast_actions: bool = False,
         seed: int = 0,
         env_indices=None,
         rank: int = 0,
@@ -86,6 +87,7 @@ class TimeSeriesEnv:
         if obs_dtype not in (torch.float64, torch.float32):
             raise ValueError("obs_dtype must be torch.float64 or torch.float32")
         self.redraw = redraw
+        self.cast_actions = bool(cast_actions)
         self.seed = int(seed)
         self.obs_dtype = obs_dtype
         self.rank, self.world_size = int(rank), int(world_size)
@@ -425,7 +427,14 @@ class TimeSeriesEnv:
         that reads the actions anyway, so the policy's output can stay where the policy wrote it."""
         N, A = self.num_envs, self.num_assets
         if actions.dtype is not torch.float32:
-            actions = actions.float()  # the reference's in-repo callers all pass f32 (SURVEY App. A iii)
+            # With f64 actions the reference silently promotes its share counts and commission products to f64
+            # (TSE:298-302, 353-361) -- different bits from the f32 arithmetic every in-repo caller gets
+            # (PPO_agent.py:101-108 samples f32).  This build computes the f32 path only, so it says so instead of
+            # quietly answering a different question; cast_actions=True opts into the cast.
+            if not self.cast_actions:
+                raise ValueError(f"actions must be float32, got {actions.dtype} (the reference would promote its share "
+                                 "counts to that dtype; construct the env with cast_actions=True to have them cast to float32)")
+            actions = actions.float()
         if actions.numel() != N * A or actions.device != self._dev:
             raise ValueError(f"actions must hold {N}x{A} values on {self.device}, got {tuple(actions.shape)} on {actions.device}")
         if not actions.is_contiguous():

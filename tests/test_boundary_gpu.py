@@ -268,3 +268,22 @@ def test_two_envs_on_two_streams_do_not_interfere(fe, fo):
         for k in range(len(acts)):
             assert torch.equal(rews[i][k], alone[i][0][k]), f"env {i} step {k} rewards"
         assert torch.equal(last[i], alone[i][1]) and torch.equal(envs[i].cash, alone[i][2])
+
+
+def test_non_f32_actions_are_refused_unless_cast(fe, fo):
+    """With f64 actions the reference promotes its share counts and commission products to f64 (TSE:298-302,
+    353-361): different arithmetic from the f32 path this build computes.  Refused by default; cast_actions=True
+    opts into the cast and then equals the f32 call bit for bit."""
+    P, LR = _tables(fo, 5, 1, 40, 8)
+    a64 = (torch.rand((12, 1), generator=torch.Generator().manual_seed(3), dtype=torch.float64) * 2 - 1).cuda()
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=8, num_envs=12, evaluate=True)
+    with pytest.raises(ValueError, match="float32"):
+        env.step(a64)
+    with pytest.raises(ValueError, match="float32"):
+        env.step(a64.half())
+    o32, r32, d32, _ = env.step(a64.float())  # the refused calls changed nothing
+    env2 = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=8, num_envs=12, evaluate=True, cast_actions=True)
+    o, r, d, _ = env2.step(a64)
+    assert_bits(t2n(o), t2n(o32), "obs")
+    assert_bits(t2n(r), t2n(r32), "rewards")
+    assert_bits(t2n(d), t2n(d32), "dones")

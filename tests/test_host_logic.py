@@ -144,6 +144,37 @@ def test_bench_helpers_and_cli_parse_without_a_gpu():
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
 
 
+def test_bench_never_nests_a_profiler(monkeypatch):
+    """bench.py's live counter passes start `rocprofv3 --pmc` children.  Under a profiler (rocprofv3 preloads a tool
+    library and sets ROCP_TOOL_LIBRARIES) the child would inherit it and exec after GPU initialisation -- the case that
+    takes a box of this pool down.  So: detect it and skip, and scrub the children's environment."""
+    import importlib.util
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    clean = {"PATH": "/usr/bin", "LD_PRELOAD": "/usr/lib/libjemalloc.so", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+    assert not bench.under_profiler(clean)
+    for dirty in ({"ROCP_TOOL_LIBRARIES": "/opt/rocm/lib/librocprofiler-sdk-tool.so"},
+                  {"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so:/usr/lib/libjemalloc.so"},
+                  {"HSA_TOOLS_LIB": "libfoo.so"}):
+        assert bench.under_profiler(dict(clean, **dirty)), dirty
+    env = bench.pmc_child_env(dict(clean, ROCP_TOOL_LIBRARIES="x", ROCPROF_OUTPUT_PATH="y", ROCPROFILER_LIBRARY_CTOR="1",
+                                   LD_PRELOAD="/opt/rocm/lib/librocprofiler-sdk-tool.so:/usr/lib/libjemalloc.so"))
+    assert env["LD_PRELOAD"] == "/usr/lib/libjemalloc.so" and env["TMPDIR"] == "/tmp"
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"  # what multi-process GPU work needs stays
+    assert not [k for k in env if k.startswith(("ROCP_", "ROCPROF"))]
+    assert "LD_PRELOAD" not in bench.pmc_child_env({"LD_PRELOAD": "librocprofiler-sdk-tool.so"})
+    # under a profiler the live pass refuses before it looks for rocprofv3, and remembers it for later workloads
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/librocprofiler-sdk-tool.so")
+    t, why = bench.live_pmc_traffic(2, False, "device")
+    assert t is None and "profiler" in why
+    monkeypatch.delenv("ROCP_TOOL_LIBRARIES")
+    assert bench.live_pmc_traffic(2, False, "device") == (None, why)
+
+
 def test_trajectory_state_descriptor_protocol_on_host_tensors():
     """TrajectoryBuffer(states=True) without a GPU (host_rehearsal): packed layout, begin / state_slot order, the
     bootstrap row carried into the next chunk, capacity padding, errors."""
