@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-VARIANT_KNOBS = ("FE_MIN_WAVES_PER_EU", "FE_STORE_AUX", "FE_ROLLOUT_WAVES", "FE_ROLLOUT_NOPOLICY", "FE_STEP_VARIANT", "FE_ABLATE", "FE_STAMP", "FE_SYNC", "FE_GEOM_R01", "FE_HOIST_FIRST", "FE_F32_WAVES", "FE_NO_DESC", "FE_XCD_BLOCKED", "FE_LSTM_BIG_RI", "FE_LSTM_BIG_AHEAD", "FE_LSTM_SPLIT_AHEAD", "FE_LSTM_BIG_PIN", "FE_STEP_PIN", "FE_MLP_PIN", "FE_LSTM_PIN", "FE_HOIST_ALL")
+VARIANT_KNOBS = ("FE_HOIST_FIRST", "FE_F32_WAVES", "FE_STAMP", "FE_X")  # live tunables of fe_device_common.h (+ the temporary stamp build)
 
 
 def build_variant(tag: str, defines: dict, verbose: bool = False) -> str:

@@ -10,97 +10,44 @@
 namespace {
 
 constexpr int kBlock = 256;
-// Single-asset kernels: 7 waves per SIMD = 72 VGPRs, the most they reach without scratch spills
-// (8 spills 12-36 B/lane and measured slower); the 20 KiB LDS stage allows 7 workgroups per CU too.
-// Multi-asset kernels carry the per-sleeve LDS arrays (26 KiB at 8 envs x 30 assets -> 6 per CU),
-// so they are built for 6 waves per SIMD (80 VGPRs, no spills).
-#ifndef FE_MIN_WAVES_PER_EU
-#define FE_MIN_WAVES_PER_EU 7
-#endif
-// Cache policy of the observation stores (raw buffer stores, aux bits: 1 = sc0, 2 = nt, 16 = sc1).
-// -2 (default) = chosen per kernel variant; in both cases the point is that a 0.17-150 GB store stream must not
-// evict what phase 1 and phase 2 re-read every step from the 4 MiB L2s:
-//   * single-asset envs: sc1 (write-through, the line is dropped from L2).  The per-env state, the action and
-//     the tables then stay L2-resident, which shortens the kernel's start-up chain (index load -> bar gather ->
-//     accounting -> first store): measured at 64k envs (tools/ab_step.py, interleaved in one process, three
-//     boxes) 34.8 -> 31.1, 34.5 -> 32.0, 34.8 -> 33.6 us per step; nt gains about 1 % less, sc0|sc1 the same.
-//   * multi-asset envs: nt.  Measured at 1M envs x 30 assets (round 1, profiles/r01_microbench/store_policy.txt): FETCH_SIZE
+// Wavefronts per SIMD the streaming kernels are built for.  Reset / render: 7 (72 VGPRs; the 20 KiB LDS stage allows
+// 7 workgroups per CU too).  Multi-asset step: 6 (80 VGPRs; the per-sleeve LDS arrays -- 26 KiB at 8 envs x 30 assets
+// -- allow 6 per CU).  Single-asset step: see kEnvKernelWaves (fe_step_kernel.h).
+constexpr int kRenderWaves = 7;
+constexpr int kMultiAssetWaves = 6;
+// Cache policy of the observation stores (raw buffer stores, aux bits: 1 = sc0, 2 = nt, 16 = sc1).  A 0.17-150 GB store
+// stream must not evict what phase 1 and phase 2 re-read every step from the 4 MiB L2s:
+//   * single-asset envs: sc1 (write-through, the line is dropped from L2).  The per-env state, the action and the
+//     tables then stay L2-resident, which shortens the kernel's start-up chain (index load -> bar gather -> accounting
+//     -> first store): measured at 64k envs (round 2, interleaved in one process, three boxes) 34.8 -> 31.1,
+//     34.5 -> 32.0, 34.8 -> 33.6 us per step; nt gains about 1 % less, sc0|sc1 the same.
+//   * multi-asset envs: nt.  Measured at 1M envs x 30 assets (profiles/r01_microbench/store_policy.txt): FETCH_SIZE
 //     6.9 GiB -> 0.4 GiB per launch and 26.4 -> 25.0 ms; sc1 gives the same fetch reduction but 25.6 ms.
-// -1 = plain everywhere; -3 = the round-1 choice (plain for single-asset, nt for multi-asset); >= 0 = that aux
-// everywhere (experiment builds).
-// "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their
-// -D set here and are only ever loaded by explicit path
-#ifndef FE_LSTM_BIG_RI   /* large-H LSTM kernel: row tiles per iteration / k groups of weights in flight (experiment builds vary them) */
-#define FE_LSTM_BIG_RI 4
-#endif
-#ifndef FE_LSTM_BIG_AHEAD
-#define FE_LSTM_BIG_AHEAD 2
-#endif
-#ifndef FE_HOIST_ALL   /* single-asset f64 step kernel: every tile's table tuples are loaded one tile ahead */
-#define FE_HOIST_ALL 0
-#endif
-#ifndef FE_LSTM_PIN
-#define FE_LSTM_PIN 0
-#endif
-#ifndef FE_MLP_PIN
-#define FE_MLP_PIN 0
-#endif
-#ifndef FE_STEP_PIN
-#define FE_STEP_PIN 0
-#endif
-#ifndef FE_LSTM_BIG_PIN
-#define FE_LSTM_BIG_PIN 0
-#endif
-#ifndef FE_LSTM_SPLIT_AHEAD
-#define FE_LSTM_SPLIT_AHEAD 16
-#endif
-#ifndef FE_XCD_BLOCKED   /* experiment builds only: XCD-blocked tile order in the step / reset kernels */
-#define FE_XCD_BLOCKED 0
-#endif
-#ifndef FE_NO_DESC   /* experiment builds only: compile the step kernel's descriptor outputs out (A/B of their cost) */
-#define FE_NO_DESC 0
-#endif
+constexpr int kStoreAuxSingle = 16;
+constexpr int kStoreAuxMulti = 2;
+// "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their -D set here
+// and are only ever loaded by explicit path
 #ifndef FE_BUILD_TAG
 #define FE_BUILD_TAG ""
 #endif
-#ifndef FE_STORE_AUX
-#define FE_STORE_AUX -2
-#endif
-// Structure of the single-asset step kernel (experiments; tools/ab_step.py):
-//   0  software pipeline: per tile [account (wave 0) | barrier | stream (4 waves) | barrier], next tile's
-//      loads prefetched under the stream
-//   1  up-front accounting: wave w accounts the workgroup's w-th tile, all four at once; one barrier; then the
-//      workgroup streams its tiles back to back with no further barriers
-//   2  the north star's literal "one wavefront per env": lane 0 of a wavefront accounts one env, then the
-//      wavefront streams that env's observation; no workgroup barriers at all (measured A/B for DESIGN.md)
-#ifndef FE_STEP_VARIANT
-#define FE_STEP_VARIANT 0
-#endif
-// Timing-only ablations of the step kernel (WRONG outputs; experiment builds only -- tools/ab_step.py):
-//   bit 0  no phase 1: descriptors fabricated from the env number, no state / bar loads, no write-back
-//   bit 1  no table loads in phase 2 (the image is built from constants)
-//   bit 2  no LDS transpose in phase 2 (registers stored directly)
-//   bit 3  phase 1 without its global stores (state write-back, reward, done)
-//   bit 4  phase 1 without its global loads (constants instead)
-//   bit 5  phase 1 without the accounting arithmetic
-//   (bits 6 / 7 -- phase 1 skipped on the first tile only / on all but the first -- were used once and removed)
-#ifndef FE_ABLATE
-#define FE_ABLATE 0
-#endif
-// Diagnostic build: every workgroup of the single-asset step kernel writes four s_memrealtime stamps (100 MHz)
-// -- start, first tile accounted, first tile streamed, end -- into the buffer bound as fe_env_bind_stats'
-// eval_return argument (grid * 8 u64; the statistics themselves are off in this build).  tools/stamp_step.py.
-#ifndef FE_STAMP
-#define FE_STAMP 0
-#endif
-// 1 (default): the single-asset f64 step kernel issues the first tile's table loads before its accounting
-// (0 = A/B arm).  Measured on a shared ring (profiles/r02_microbench/ab_hoist.txt): 30.57 -> 29.32 us at config 2.
-// Not for f32 observations: they run 6 workgroups per CU (80 VGPRs) and the 16 extra live registers spill.
+// Build knobs (experiment builds only; the product uses the defaults):
+//   FE_HOIST_FIRST  1: the single-asset f64 step kernel issues the first tile's table loads before its accounting
+//                   (profiles/r02_microbench/ab_hoist.txt: 30.57 -> 29.32 us at config 2 on a shared ring)
+//   FE_F32_WAVES    wavefronts per SIMD the single-asset f32-observation step kernel is built for
 #ifndef FE_HOIST_FIRST
 #define FE_HOIST_FIRST 1
 #endif
 #ifndef FE_F32_WAVES
 #define FE_F32_WAVES 6
+#endif
+// TEMPORARY diagnostic build (removed again after the round-3 start-up measurements, tools/stamp_step.py): every
+// workgroup of the single-asset step kernel writes s_memrealtime stamps (100 MHz) into the buffer bound as
+// fe_env_bind_stats' eval_return argument (grid * 8 u64; the statistics themselves are off in this build).
+#ifndef FE_STAMP
+#define FE_STAMP 0
+#endif
+#ifndef FE_X   /* TEMPORARY round-3 A/B bit: 2 = always the FULL step kernel */
+#define FE_X 0
 #endif
 template <typename OT>
 constexpr bool kHoistFirst = FE_HOIST_FIRST != 0 && (sizeof(OT) == 8 || FE_F32_WAVES <= 5);
@@ -209,17 +156,6 @@ __device__ __forceinline__ void lds_barrier() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup", "local");
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup", "local");
-}
-// the step kernel's barriers (FE_SYNC=1: the round-1 form, for A/B)
-#ifndef FE_SYNC
-#define FE_SYNC 0
-#endif
-__device__ __forceinline__ void tile_barrier() {
-#if FE_SYNC
-    __syncthreads();
-#else
-    lds_barrier();
-#endif
 }
 
 struct Sleeve {
@@ -340,12 +276,6 @@ __host__ __device__ inline size_t lds_bytes(int EB, int A) {
     size_t S = (size_t)EB * A;
     size_t b = 4 * (size_t)kStageBytes + (size_t)EB * 8 + S * 8;
     if (A > 1) b += S * 8 + S * 4 + S * 4 + (size_t)EB * 4;
-    else b += (size_t)EB * 8;  // window descriptors of the next tile (kHoistAll)
-#if FE_STEP_VARIANT == 1
-    if (A == 1) b = 4 * (size_t)kStageBytes + 4 * ((size_t)EB * 16);  // descriptors of four tiles at once
-#elif FE_STEP_VARIANT == 2
-    if (A == 1 && b < 4 * (size_t)kStageBytes + 64) b = 4 * (size_t)kStageBytes + 64;  // one descriptor slot per wavefront
-#endif
     return (b + 15) & ~(size_t)15;
 }
 
@@ -382,11 +312,6 @@ struct SleeveIn {
 __device__ __forceinline__ void load_head(const Params &p, bool active, int64_t n, int64_t &idx, int64_t &spot) {
     idx = 0;
     spot = 0;
-#if FE_ABLATE & 16
-    idx = n % p.D;
-    spot = 1;
-    return;
-#endif
     if (active) {
         idx = p.env_idx[n];
         spot = p.spot0[n];
@@ -397,10 +322,6 @@ __device__ __forceinline__ void load_head(const Params &p, bool active, int64_t 
 // workgroup's first tile, so that only the L2-resident bar gather sits behind the index load)
 __device__ __forceinline__ void load_state(const Params &p, bool active, int64_t sl, SleeveIn &in) {
     if (!active) return;
-#if FE_ABLATE & 16
-    in.cash = 1e4f; in.lng = (float)(sl & 3); in.sht = 0.0f; in.margin = 0.0;
-    return;
-#endif
     in.cash = p.cash[sl];
     in.lng = p.lng[sl];
     in.sht = p.sht[sl];
@@ -411,11 +332,6 @@ __device__ __forceinline__ void load_state(const Params &p, bool active, int64_t
 __device__ __forceinline__ void load_bar(const Params &p, int A, int a, bool active, int64_t idx, int64_t spot,
                                          SleeveIn &in) {
     if (!active) return;
-#if FE_ABLATE & 16
-    in.idx = idx; in.s0 = spot + 1; in.nxt = spot + p.W + 1; in.bar = make_double4(100.0, 101.0, 99.0, 100.5);
-    in.probe = 0.0;
-    return;
-#endif
     const int64_t rs = 4 * (int64_t)A;
     const int64_t L = p.L;
     in.idx = idx;

@@ -114,11 +114,13 @@ static int device_of(const void *ptr) {
     return attr.device;
 }
 
-// The kernel instantiation a given env dispatches to (shared by launch and occupancy query).
-template <bool RESET_ONLY>
+// The kernel instantiation a given env dispatches to (shared by launch and occupancy query).  FULL: the launch has
+// optional outputs (evaluate-mode bookkeeping, episode statistics, trajectory descriptors / action copy); the lean
+// form is the same kernel without them (same launch bounds, same LDS).
+template <bool RESET_ONLY, bool FULL>
 static const void *kernel_for(bool f32, int vec, bool single) {
 #define FE_PICK(OT, VEC) \
-    (single ? (const void *)fe_env_kernel<OT, VEC, true, RESET_ONLY> : (const void *)fe_env_kernel<OT, VEC, false, RESET_ONLY>)
+    (single ? (const void *)fe_env_kernel<OT, VEC, true, RESET_ONLY, FULL> : (const void *)fe_env_kernel<OT, VEC, false, RESET_ONLY, FULL>)
     if (f32) return vec == 4 ? FE_PICK(float, 4) : (vec == 2 ? FE_PICK(float, 2) : FE_PICK(float, 1));
     return vec == 2 ? FE_PICK(double, 2) : FE_PICK(double, 1);
 #undef FE_PICK
@@ -140,8 +142,11 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     void *args[] = {&p};
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
-    hipError_t he = hipLaunchKernel(kernel_for<RESET_ONLY>(env->cfg.obs_is_f32 != 0, env->vec, p.A == 1),
-                                    dim3(env->grid), dim3(kBlock), args, env->lds, st);
+    const bool f32 = env->cfg.obs_is_f32 != 0, single = p.A == 1;
+    const bool full = !RESET_ONLY && ((FE_X & 2) || p.evaluate || p.run_ret || desc_src || act_store);
+    const void *kern = RESET_ONLY ? kernel_for<true, false>(f32, env->vec, single)
+                                  : (full ? kernel_for<false, true>(f32, env->vec, single) : kernel_for<false, false>(f32, env->vec, single));
+    hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, env->lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");
     return FE_OK;
 }
@@ -150,12 +155,9 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
 static int configure_launch(fe_env *env) {
     const fe_config &cfg = env->cfg;
     const int A = cfg.A;
-    const void *kern = kernel_for<false>(cfg.obs_is_f32 != 0, env->vec, A == 1);
+    const void *kern = kernel_for<false, true>(cfg.obs_is_f32 != 0, env->vec, A == 1);
     // How many workgroups the chip holds at once for this kernel variant (registers + LDS).
     int64_t cap = kBlock / A > 0 ? kBlock / A : 1;  // one sleeve per lane in phase 1
-#if FE_STEP_VARIANT == 1
-    if (A == 1) cap = 64;  // a tile is accounted by one wavefront
-#endif
     int per_cu = 0;
     hipError_t he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds_bytes((int)cap, A));
     if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor");
@@ -170,10 +172,7 @@ static int configure_launch(fe_env *env) {
     if (EB < 1) EB = 1;
     if (EB > cap) EB = cap;
     int wgs_per_cu = 0;  // 0 = whatever the occupancy query allows
-#ifndef FE_GEOM_R01   /* experiment builds only: the round-1 geometry rule for every shape */
-#define FE_GEOM_R01 0
-#endif
-    if (A == 1 && !FE_GEOM_R01) {
+    if (A == 1) {
         // Single-asset envs (measured at 64k envs x W64 on a shared observation ring, tools/ab_step.py,
         // profiles/r02_microbench/sweep{3,4}_c2.txt, sweep_f32_c2.txt).  A tile must be a whole number of workgroup
         // iterations of phase 2 (4 wavefronts x one 5-KiB image = 512 f64 / 1024 f32 tuples): with f64 observations
@@ -187,7 +186,7 @@ static int configure_launch(fe_env *env) {
         while (w) { const int64_t t = g % w; g = w; w = t; }  // gcd(wg_tuples, W)
         const int64_t unit = wg_tuples / g;                  // envs per whole workgroup iteration
         if (unit <= cap) {
-            wgs_per_cu = cfg.obs_is_f32 ? (FE_F32_WAVES < 6 ? FE_F32_WAVES : 6) : 4;
+            wgs_per_cu = cfg.obs_is_f32 ? (env->vec == 4 ? kF32StepWaves<float, 4> : kF32StepWaves<float, 1>) : 4;
             const int64_t res = (int64_t)env->cus * wgs_per_cu;
             if (resident > res) resident = res;
             // tiles per workgroup aimed at: 8 (f64) resp. 4/3 (f32)

@@ -24,6 +24,11 @@ namespace {
 //     action BIT FOR BIT; against torch's own nn.LSTM the actions agree to ~1e-7.
 // One barrier per time step (h double-buffered in LDS); the last hidden state is reduced by the pair's accounting lane.
 constexpr int kLstmBlock = 512;
+// large-H kernel: row tiles run together (independent accumulator chains per B fragment) / k groups of weight
+// fragments in flight; split kernel: k groups of h in flight (profiles/r02_microbench/lstm_*.txt)
+constexpr int kLstmBigRI = 4;
+constexpr int kLstmBigAhead = 2;
+constexpr int kLstmSplitAhead = 16;
 
 struct LstmArgs {
     const float *lr32;  // (D, L, 4A) f32 copy of the log-return table
@@ -225,7 +230,7 @@ __global__ __launch_bounds__(kLstmBlock, (NT == 1 ? 4 : 2)) void fe_rollout_lstm
                     xn[j] = half == 0 ? *reinterpret_cast<const float4 *>(xsrc[j] + (int64_t)tn * rstride) : xh[j];
                 // keep the next time step's row loads up here (the scheduler otherwise sinks them towards their use): -6.5 % at
                 // H = 128, -1 % at 64, +1.5 % at 32 (tools/fused_bench.py with FUSED_LIB=lstmpin)
-                if constexpr (NT >= 2 || FE_LSTM_PIN) __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NT >= 2) __builtin_amdgcn_sched_barrier(0);
                 // JB column tiles at a time: with MPW row tiles that is MPW * JB >= 2 independent accumulator chains,
                 // so a dependent MFMA never waits for its predecessor's 16 passes
 #pragma unroll
@@ -363,8 +368,8 @@ __host__ __device__ inline size_t lstm_big_lds_bytes(int EB, int A, int H) {
 template <bool SINGLE, int RTW>
 __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(const Params p, const LstmArgs r) {
     constexpr int H = 64 * RTW, HP = H + 4, NG = H / 8, SP = 32;
-    constexpr int RI = FE_LSTM_BIG_RI;  // row tiles run together: RI independent accumulator chains share every B fragment
-    constexpr int AHEAD = FE_LSTM_BIG_AHEAD;  // k groups a weight fragment is loaded ahead of its MFMAs
+    constexpr int RI = kLstmBigRI;  // row tiles run together: RI independent accumulator chains share every B fragment
+    constexpr int AHEAD = kLstmBigAhead;  // k groups a weight fragment is loaded ahead of its MFMAs
     static_assert(RTW % RI == 0 && (H / 8) % AHEAD == 0, "row tiles / k groups must come in whole groups");
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
@@ -386,7 +391,7 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
     const int64_t NA = p.N * A;
     const int64_t rstride = 4 * (int64_t)A;
     const int mt0 = wave * RTW;  // this wavefront's row tiles: mt0 .. mt0 + RTW - 1
-    float4 wq[FE_LSTM_BIG_AHEAD][FE_LSTM_BIG_RI];  // weight fragments in flight (see the k loop)
+    float4 wq[kLstmBigAhead][kLstmBigRI];  // weight fragments in flight (see the k loop)
     bool primed = false;
     for (int i = tid; i < H; i += kLstmBlock) s_wout[i] = r.wout[i];
 
@@ -476,9 +481,6 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
                                     wv[i] = wq[d][i];
                                     wq[d][i] = gn < NG ? wf[i][(size_t)gn * 64] : wfn[i][(size_t)(gn - NG) * 64];
                                 }
-#if FE_LSTM_BIG_PIN
-                                __builtin_amdgcn_sched_barrier(0);  // keep the refill loads AHEAD groups before their use
-#endif
                                 const float4 hb = *reinterpret_cast<const float4 *>(hrow + 8 * g);
 #pragma unroll
                                 for (int m = 0; m < 4; ++m) {
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Param
     const size_t frag = (size_t)CT * NG * 64;  // float4s per h buffer
     float4 *hnext = reinterpret_cast<float4 *>(s.hbuf) + (size_t)(t & 1) * frag;
     const float4 *hprev = reinterpret_cast<const float4 *>(s.hbuf) + (size_t)((t + 1) & 1) * frag + ((size_t)ctc * NG) * 64 + lane;
-    constexpr int AHEAD = FE_LSTM_SPLIT_AHEAD;  // k groups of h in flight (h was written by the previous launch: also cold)
+    constexpr int AHEAD = kLstmSplitAhead;  // k groups of h in flight (h was written by the previous launch: also cold)
     float4 hq[AHEAD];
     if (t > 0) {
 #pragma unroll

@@ -185,11 +185,8 @@ __host__ __device__ inline size_t rollout_lds_bytes(int EB, int A, int W) {
     return (b + 15) & ~(size_t)15;
 }
 
-#ifndef FE_ROLLOUT_WAVES
-#define FE_ROLLOUT_WAVES 1
-#endif
 template <bool SINGLE>
-__global__ __launch_bounds__(kBlock, FE_ROLLOUT_WAVES) void fe_rollout_linear_kernel(const Params p, const RolloutArgs r) {
+__global__ __launch_bounds__(kBlock, 1) void fe_rollout_linear_kernel(const Params p, const RolloutArgs r) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
@@ -224,10 +221,6 @@ __global__ __launch_bounds__(kBlock, FE_ROLLOUT_WAVES) void fe_rollout_linear_ke
         const int pairs = ebt * A;
         for (int k = 0; k < r.K; ++k) {
             // policy: one wavefront per (env, asset) pair of the tile
-#ifdef FE_ROLLOUT_NOPOLICY  /* diagnostic build: how long is a step without the policy? */
-            for (int q = tid; q < pairs; q += kBlock) s_act[q] = (float)r.bias;
-            if (false)
-#endif
             for (int q = wave; q < pairs; q += kBlock / 64) {
                 const int ee = SINGLE ? q : (int)fdiv((uint32_t)q, p.div_A);
                 const int aa = SINGLE ? 0 : q - ee * A;
@@ -499,7 +492,7 @@ __device__ __forceinline__ void mlp_policy_block(const Params &p, const MlpArgs 
         for (int i = 0; i < CH; ++i) xn[i] = load_x((c + 1) * CH + i);
         // keep the next chunk's row loads ahead of this chunk's MFMAs: left alone the scheduler sinks them towards their use,
         // which costs 6 - 7 % at H = 128 (neutral at H = 32 / 64; tools/fused_bench.py with FUSED_LIB=mlppin)
-        if constexpr (NT == 4 || FE_MLP_PIN) __builtin_amdgcn_sched_barrier(0);
+        if constexpr (NT == 4) __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int i = 0; i < CH; ++i) {
             float4 wa[NT];

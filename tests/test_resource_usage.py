@@ -1,0 +1,67 @@
+"""CPU (cross-compile only): no scratch memory in the step / reset / render kernels.
+
+hipcc reports registers and scratch per kernel (-Rpass-analysis=kernel-resource-usage).  A streaming kernel that
+spills keeps part of its software pipeline in memory behind the very store stream it is trying to feed; round 2's
+f32 single-asset step kernels did (40 - 212 bytes per lane) while a comment claimed otherwise.  The table of this
+build is committed as profiles/r03_resource_usage.txt (tools/resource_usage.py --out ...).
+"""
+import os
+import re
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def table():
+    import resource_usage
+
+    from finenvs_amd.csrc import build as hip_build
+
+    if not os.path.exists(hip_build.HIPCC):
+        pytest.skip("hipcc not available")
+    return resource_usage.kernel_table()
+
+
+def test_streaming_kernels_use_no_scratch(table):
+    streaming = [r for r in table if re.match(r"fe_(env|render|describe)_kernel", r["name"])]
+    # 5 (dtype x pack width) x 2 (single / multi asset) x (reset + lean step + full step), + render and describe
+    assert len([r for r in streaming if r["name"].startswith("fe_env_kernel")]) == 30
+    assert len([r for r in streaming if r["name"].startswith("fe_render_kernel")]) == 10
+    bad = [(r["name"], r["scratch"], r["vgpr_spill"]) for r in streaming if r["scratch"] != 0 or r["vgpr_spill"] != 0]
+    assert not bad, f"scratch / VGPR spills in streaming kernels: {bad}"
+
+
+def test_step_kernels_keep_their_occupancy(table):
+    """The launch geometry (fe_env.hip:configure_launch) assumes these wavefronts per SIMD."""
+    want = {
+        "fe_env_kernel<double, 2, true, false, false>": 4,   # single asset, f64: 4 workgroups per CU
+        "fe_env_kernel<float, 4, true, false, false>": 6,    # single asset, f32: 6
+        "fe_env_kernel<double, 2, false, false, false>": 6,  # multi asset
+        "fe_env_kernel<double, 2, true, true, false>": 7,    # reset()
+    }
+    got = {r["name"]: r["occupancy"] for r in table}
+    for name, waves in want.items():
+        assert got[name] >= waves, (name, got[name], waves)
+
+
+def test_lean_step_kernel_has_fewer_scalar_spills_than_the_full_one(table):
+    """fe_env_kernel<..., FULL = false> exists so that the optional outputs' pointers never become live scalars
+    (profiles/r03_microbench/lean_vs_full.txt): 48 SGPR spills in round 2's only form, ~10 in the lean one."""
+    got = {r["name"]: r["sgpr_spill"] for r in table}
+    assert got["fe_env_kernel<double, 2, true, false, false>"] <= 16
+    assert got["fe_env_kernel<double, 2, true, false, false>"] < got["fe_env_kernel<double, 2, true, false, true>"]
+
+
+def test_committed_table_matches_this_build(table):
+    path = os.path.join(ROOT, "profiles", "r03_resource_usage.txt")
+    text = open(path).read()
+    for r in table:
+        if r["name"].startswith(("fe_env_kernel", "fe_render_kernel")):
+            line = next((ln for ln in text.splitlines() if ln.startswith(r["name"][:58] + " ")), None)
+            assert line is not None, f"{r['name']} missing from {path}: regenerate it"
+            cols = line[58:].split()
+            assert int(cols[3]) == r["scratch"], (r["name"], line)
