@@ -265,11 +265,56 @@ class Dist:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
             kw = {"timeout": datetime.timedelta(minutes=5)}
+            # RCCL's own account of what it chose (algorithm / protocol / channels) goes to a per-process file that rank 0
+            # summarises into multi_gpu.rccl (NCCL_DEBUG_FILE keeps it off stdout / stderr); FE_BENCH_RCCL_DEBUG=0 switches it off
+            self.rccl_log = None
+            if self.backend == "nccl" and os.environ.get("FE_BENCH_RCCL_DEBUG", "1") != "0":
+                self.rccl_log = f"/tmp/fe_bench_rccl_{os.getpid()}.log"
+                os.environ["NCCL_DEBUG"] = "INFO"
+                os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING,ENV,COLL"
+                os.environ["NCCL_DEBUG_FILE"] = self.rccl_log
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device(self.dev), **kw)
             else:
                 dist.init_process_group(self.backend, **kw)
             self.dist = dist
+
+    def rccl_report(self):
+        """What RCCL said about itself on this rank (NCCL_DEBUG=INFO into a file): version, topology / channel lines and
+        every distinct algorithm / protocol decision it logged.  None when the backend is not RCCL or logging is off."""
+        path = getattr(self, "rccl_log", None)
+        if not path:
+            return None
+        path = os.environ.get("NCCL_DEBUG_FILE", path)
+        try:
+            with open(path, errors="replace") as f:
+                lines = [ln.strip() for ln in f]
+        except OSError as exc:
+            return {"log": path, "error": f"{type(exc).__name__}: {exc}"}
+        import re
+
+        def pick(pat, limit):
+            seen, out = set(), []
+            for ln in lines:
+                if re.search(pat, ln, re.I):
+                    body = re.sub(r"^\S+:\d+:\d+ \[\d+\] NCCL INFO ", "", ln)[:200]
+                    if body not in seen:
+                        seen.add(body)
+                        out.append(body)
+                    if len(out) >= limit:
+                        break
+            return out
+
+        return {"log_lines": len(lines),
+                "version": pick(r"RCCL version|HIP version|ROCm version", 3),
+                # with more than one rank the TUNING subsystem logs its choice per collective size ("... Bytes -> Algo A proto P")
+                "algorithm_protocol": pick(r"-> Algo|Algo \d|algorithm|protocol|Bytes ->", 12) or
+                                      ["(none logged: RCCL logs no algorithm / protocol choice for a single rank)"],
+                "topology": pick(r"Pattern \d|coll channels|P2P Chunksize|intraNodeP2pSupport|nNodes|XGMI|=== System", 10),
+                "transport": pick(r" via |Connected all", 6),
+                "rings": pick(r"NCCL INFO Ring 0*0 :", 2),
+                "all_gather_calls": len([1 for ln in lines if "NCCL INFO AllGather:" in ln]),
+                "env": pick(r"NCCL_[A-Z_]+ set|RCCL_[A-Z_]+ set", 8)}
 
     def barrier(self):
         if self.dist is not None:
@@ -289,6 +334,35 @@ class Dist:
         t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=self.dev if self.backend == "nccl" else "cpu")
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
         return bool(t.item() > 0.5)
+
+
+def kernel_interval_ms(env, actions, k2: int, runs: int = 3, all_runs: bool = False):
+    """Average launch interval of the step kernel: k2 launches issued straight through the C ABI (preallocated outputs,
+    no per-step Python work) so the queue never drains, bracketed by ONE pair of HIP events on the launch stream (torch's
+    current stream is the stream the C ABI launches on); the interval = kernel + the ~1.5 us launch boundary.  Uses the
+    env's own observation ring (keeps the HBM / MALL regime of the timed region).  Median of `runs` (or all of them)."""
+    from finenvs_amd import _lib as _fl
+
+    N, dev = env.num_envs, env._dev
+    stream = torch.cuda.current_stream().cuda_stream
+    obs_b = [t.data_ptr() for t in env._obs_ring]
+    nb = len(obs_b)
+    rew_b = torch.empty((N,), dtype=torch.float64, device=dev)
+    done_b = torch.empty((N,), dtype=torch.int32, device=dev)
+    aptr = [a.data_ptr() for a in actions]
+    fn, h = env._step_fn, env._handle_v
+    out = []
+    for _ in range(runs):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for i in range(k2):
+            rc = fn(h, aptr[i % 8], obs_b[i % nb], rew_b.data_ptr(), done_b.data_ptr(), stream)
+        e1.record()
+        torch.cuda.synchronize()
+        _fl.check(rc)
+        out.append(e0.elapsed_time(e1) / k2)
+    return out if all_runs else statistics.median(out)
 
 
 def auto_repeats(repeats: int, steps: int, est_step_s: float) -> int:
@@ -315,16 +389,30 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         # config 4's observation is 153.6 GB: a single env-owned buffer (SURVEY section 7 "Capacity")
         obs_bytes = n_per_gpu * W * 5 * A * obs_elem
         obs_buffers = 2 if 2 * obs_bytes < 200e9 else 1
+        # the previous workload's buffers (and those of its rocprofv3 child processes) are given back asynchronously:
+        # a 150 GB allocation can take seconds to reappear as free memory after its owner has gone
+        need = obs_buffers * obs_bytes + (6 << 30)
+        t_wait = time.perf_counter()
+        while torch.cuda.mem_get_info(D.dev)[0] < need and time.perf_counter() - t_wait < 60.0:
+            gc.collect()
+            torch.cuda.empty_cache()
+            time.sleep(0.5)
         env = finenvs_amd.TimeSeriesEnv(
             prices=prices, day_id=day_id, num_intervals=W, num_envs=n_per_gpu * world, rank=rank, world_size=world,
             device_id=D.local_rank, redraw=args.redraw, seed=1234, obs_buffers=obs_buffers,
-            # ring mode's placement audition (a product feature of the ring): up to 5 more candidate
-            # buffers than the ring needs are tried at construction and the fastest kept (none fit at config 4)
-            obs_audition=0 if args.no_audition else 5,
             obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
         N = env.num_envs
         g = torch.Generator(device=dev).manual_seed(7 + rank)
         actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
+        # The ring as the allocator handed it out is timed FIRST (`as_allocated`); then ring mode's placement audition (a
+        # product feature of the ring) tries up to 5 more candidate buffers and keeps the fastest
+        # (none fit at config 4) -- the headline runs on the auditioned ring, the as-allocated figure is reported beside it.
+        as_allocated = None
+        if not args.no_audition:
+            env.reset()
+            kernel_interval_ms(env, actions, 8, runs=1)  # warm the tables / state
+            as_allocated = {"kernel_ms": kernel_interval_ms(env, actions, min(max(steps, 20), 400), runs=3)}
+            env.audition_ring(5)
         # Compact trajectory fields live in a device buffer; the step kernel writes rewards, dones and its copy of the
         # actions straight into slot t (fe_env_step_traj), so storing a step costs no extra launch.  (Round 2 found the
         # earlier scheme -- actions pre-stored in the slots -- to read 256 KB of COLD memory per step once a chunk is longer
@@ -418,34 +506,33 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         traj.clear()
         legs["no_all_gather"] = timed_blocks(R)
         head = legs["with_all_gather"]
+        # Gather-only leg: the all-gather of one filled chunk ALONE (issue + drain between fences, no env steps beside
+        # it), so that "with / without all-gather" above can be decomposed: an exposed gather shows up as
+        # with - without ~ gather_only, a hidden one as with ~ without.  SURVEY section 5 expects the direct
+        # (all-links) algorithm on the fully connected xGMI node; `bus_GBps` = inbound bytes per GPU / time.
+        fence()
+        traj.clear()
+        run_steps(T)  # a full chunk of real data
+        gather_only = []
+        for _ in range(max(R, 5)):
+            fence()
+            t0 = time.perf_counter()
+            traj.mark_filled(T)  # the chunk counts as full again (same bytes; the data is not the point)
+            traj.all_gather_async()
+            traj.drain()
+            torch.cuda.synchronize()
+            gather_only.append(D.max_over_ranks(time.perf_counter() - t0))
+        fence()
+        traj.clear()
     else:
         legs["single_gpu"] = timed_blocks(R)
         head = legs["single_gpu"]
     block = statistics.median(head)
 
-    # Kernel duration for the roofline: k2 launches issued straight through the C ABI (preallocated
-    # outputs, no per-step Python work) so the queue never drains, bracketed by ONE pair of HIP events on
-    # the launch stream (torch's current stream is the stream the C ABI launches on); the average interval
-    # = kernel + the ~1.5 us launch boundary.
+    # Kernel duration for the roofline (kernel_interval_ms): launches issued straight through the C ABI, one pair of
+    # HIP events on the launch stream around them.
     k2 = min(max(steps, 20), 400)
-    stream = torch.cuda.current_stream().cuda_stream
-    obs_b = [t.data_ptr() for t in env._obs_ring]  # same ring as the timed region (keeps the HBM/MALL regime)
-    nb = len(obs_b)
-    rew_b = torch.empty((N,), dtype=torch.float64, device=dev)
-    done_b = torch.empty((N,), dtype=torch.int32, device=dev)
-    aptr = [a.data_ptr() for a in actions]
-    fn, h = env._step_fn, env._handle_v
-    kern = []
-    for _ in range(3):
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        torch.cuda.synchronize()
-        e0.record()
-        for i in range(k2):
-            rc = fn(h, aptr[i % 8], obs_b[i % nb], rew_b.data_ptr(), done_b.data_ptr(), stream)
-        e1.record()
-        torch.cuda.synchronize()
-        _fl.check(rc)
-        kern.append(e0.elapsed_time(e1) / k2)
+    kern = kernel_interval_ms(env, actions, k2, runs=3, all_runs=True)
     kern_ms = statistics.median(kern)
 
     total_envs = env.global_num_envs if world > 1 else N
@@ -461,6 +548,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         "steps": steps, "warmup": warmup,
         "envs_per_gpu": N, "num_assets": A, "window": W, "obs_buffers": obs_buffers,
         "obs_ring_audition": getattr(env, "obs_audition", None),
+        "as_allocated": as_allocated,
         "launch": env.launch_info(),
         "launch_mode": "hipGraph x8 steps" if args.graph else "eager, one launch per step",
         "repeats": {name_: {"blocks": len(v), "ms_per_step_median": statistics.median(v) / steps * 1e3,
@@ -490,14 +578,63 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             "gathered_bytes_per_rank_per_chunk": traj._nbytes * world,
             "value_with_all_gather": res["repeats"]["with_all_gather"]["value_median"],
             "value_no_all_gather": res["repeats"]["no_all_gather"]["value_median"],
+            # decomposition: one chunk's all-gather alone, and what it costs per step if fully exposed
+            "gather_only_ms": statistics.median(gather_only) * 1e3,
+            "gather_only_ms_min": min(gather_only) * 1e3, "gather_only_ms_max": max(gather_only) * 1e3,
+            "gather_only_ms_per_step_if_exposed": statistics.median(gather_only) * 1e3 / T,
+            "gather_only_inbound_GBps_per_gpu": traj._nbytes * (D.dist.get_world_size() - 1) / statistics.median(gather_only) / 1e9,
+            "exposed_ms_per_step": res["repeats"]["with_all_gather"]["ms_per_step_median"] - res["repeats"]["no_all_gather"]["ms_per_step_median"],
+            "rccl": D.rccl_report(),
         }
     if with_cpu and rank == 0:
         res["cpu_baseline"] = cpu_baseline(A, W)
     fence()
-    del env, traj, actions, roll, rew_b, done_b, obs_b
+    del env, traj, actions, roll
     gc.collect()
     torch.cuda.empty_cache()
     return res
+
+
+REDRAW_CONTRACT = ("eval_redraw='device' (the headline): the evaluation env's day redraws come from a Philox4x32-10 counter "
+                   "inside the step kernel -- THIS BUILD's contract (finenvs_amd/rng.py, pinned against the oracle's restatement of "
+                   "the same generator, not against the reference), no host synchronisation.  eval_redraw='torch' (the class "
+                   "default, timed as `reference_semantics`): the reference's own stream -- one torch.randint on the global "
+                   "generator per finished evaluation episode, decided by a per-step host read of dones[-1] (TSE:504-513); the "
+                   "reference-generated golden fixtures pin this mode.")
+
+
+def reference_semantics_leg(args, steps: int, repeats: int = 5):
+    """What a drop-in caller of the reference's loop gets (examples/time_series/PPO_LSTM_training_SPY.py:22-30): the CLASS
+    DEFAULTS -- fresh observation / reward / done tensors per step (obs_buffers=0), redraw='torch' with the reference's
+    per-step host read of the evaluation env's done flag -- on the headline workload (config 2).  Never part of `value`."""
+    import finenvs_amd
+
+    name, N, A, W = CONFIGS[2]
+    prices, day_id, _ = make_series(A)
+    torch.manual_seed(1234)
+    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, device_id=0)
+    assert env.obs_buffers == 0 and env.redraw == "torch" and env.obs_dtype == torch.float64
+    g = torch.Generator(device="cuda:0").manual_seed(7)
+    actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
+    states = env.reset()
+    for i in range(20):
+        states, _, _, _ = env.step(actions[i % 8])
+    blocks = []
+    for _ in range(repeats):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(steps):
+            states, rew, done, _ = env.step(actions[i % 8])
+        torch.cuda.synchronize()
+        blocks.append(time.perf_counter() - t0)
+    med = statistics.median(blocks)
+    del env, states
+    torch.cuda.empty_cache()
+    return {"workload": name, "what": "class defaults: obs_buffers=0 (fresh tensors per step), redraw='torch' (per-step host read, TSE:510), "
+                                      "f64 observations, eager env.step(actions) loop",
+            "value": N * steps / med, "unit": "env-steps/s", "ms_per_step": med / steps * 1e3,
+            "ms_per_step_min": min(blocks) / steps * 1e3, "ms_per_step_max": max(blocks) / steps * 1e3, "steps": steps,
+            "blocks": repeats}
 
 
 def fused_rollout_legs(args):
@@ -607,7 +744,9 @@ def main():
     measure_traffic(head, args.config)
     extras = []
     if not args.no_extra and not args.graph and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
-        wanted = ([3, 4] if not D.multi else [5])
+        # N = 1: configs 3, 4 and the per-GPU shard of config 5 (524 288 envs: the N = 1 anchor of the weak-scaling curve
+        # the 8-GPU run continues); N > 1: the config-5 shard
+        wanted = ([3, 4, 5] if not D.multi else [5])
         for c in wanted:
             if c == args.config:
                 continue
@@ -619,9 +758,13 @@ def main():
                 extras.append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
                 break
 
-    fused = None
+    fused = refsem = None
     if not D.multi and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
         fused = fused_rollout_legs(args)
+        try:
+            refsem = reference_semantics_leg(args, args.steps)
+        except Exception as exc:  # noqa: BLE001
+            refsem = {"error": f"{type(exc).__name__}: {exc}"}
 
     if D.rank == 0:
         out = {
@@ -640,7 +783,10 @@ def main():
             "config": {"workload": head["workload"], "envs_per_gpu": head["envs_per_gpu"],
                        "num_assets": head["num_assets"], "window": head["window"],
                        "obs_buffers": head["obs_buffers"], "obs_ring_audition": head["obs_ring_audition"],
-                       "eval_redraw": args.redraw,
+                       # the ring as allocated, timed before the placement audition (kernel interval and the same on the wall)
+                       "as_allocated_ms_per_step": (head["as_allocated"] or {}).get("kernel_ms"),
+                       "auditioned_kernel_ms_per_step": head["roofline"]["kernel_ms"],
+                       "eval_redraw": args.redraw, "redraw_contract": REDRAW_CONTRACT,
                        "launch_mode": head["launch_mode"], "launch": head["launch"],
                        "timed_region": "median of R blocks of exactly `steps` steps, each between (barrier + synchronize) fences, max over ranks per block"},
             "repeats": head["repeats"],
@@ -649,6 +795,7 @@ def main():
             "multi_gpu": head.get("multi_gpu"),
             "extra_configs": [{k: v for k, v in e.items() if k != "cpu_baseline"} for e in extras],
             "fused_rollouts": fused,
+            "reference_semantics": refsem,
         }
     else:
         out = None

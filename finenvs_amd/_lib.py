@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfinenvs_amd.so")
 
-FE_ABI_VERSION = 3
+FE_ABI_VERSION = 4
 FE_MAX_ASSETS = 256
 
 
@@ -46,6 +46,7 @@ SIGNATURES = {
     "fe_env_describe": (C.c_int, [_vp, _vp, _vp, _vp]),
     "fe_env_render": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "fe_env_render_n": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
+    "fe_env_check_descriptors": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64), _vp]),
     "fe_env_step_traj": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_env_rollout_linear": (C.c_int, [_vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_policy_table": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),

@@ -26,6 +26,21 @@ __global__ __launch_bounds__(kBlock) void fe_describe_kernel(const Params p, int
     }
 }
 
+// debug check of foreign descriptors (fe_env_check_descriptors): out[0] = how many are invalid, out[1] = the smallest
+// invalid index (initialised to count by the host)
+__global__ __launch_bounds__(kBlock) void fe_check_descriptors_kernel(const int64_t *__restrict__ obs_src, int64_t count,
+                                                                      int64_t row_elems, int64_t W, int64_t rows,
+                                                                      unsigned long long *out) {
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < count; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t s = obs_src[i];
+        const bool ok = s >= 0 && s % row_elems == 0 && s / row_elems + W <= rows;
+        if (!ok) {
+            atomicAdd(&out[0], 1ull);
+            atomicMin(&out[1], (unsigned long long)i);
+        }
+    }
+}
+
 // materialise the observation a pair of descriptor arrays stands for (phase 2 alone)
 template <typename OT, int VEC, bool SINGLE>
 __global__ __launch_bounds__(kBlock) void fe_render_kernel(const Params p, const int64_t *obs_src, const double *obs_pos) {

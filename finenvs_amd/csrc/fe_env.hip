@@ -37,6 +37,7 @@
 // reference's mixed f32/f64 tensor arithmetic; this file
 // must be compiled with -ffp-contract=off.
 #include <hip/hip_runtime.h>
+#include <pthread.h>
 #include <stdarg.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -112,6 +113,56 @@ static int device_of(const void *ptr) {
     }
     if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged) return -1;
     return attr.device;
+}
+
+// Host-side preparation of kernels with more than the default 64 KiB of dynamic LDS, done once instead of per call:
+// hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per (device, function) and monotone here (only ever raised, so
+// envs with different sizes cannot undercut each other), the occupancy query is cached per (device, function, block,
+// LDS).  At small env counts the fused rollouts are host-bound: the two runtime calls cost as much as a launch
+// (profiles/r03_microbench/host_prep_cache.txt).
+struct LaunchPrep {
+    int device;
+    const void *kern;
+    int block;
+    size_t lds_max;      // largest dynamic LDS size set for (device, kern) so far
+    size_t occ_lds;      // the LDS size the cached occupancy answer belongs to
+    int occ_per_cu;      // 0 = not asked yet
+};
+static LaunchPrep g_prep[64];
+static int g_nprep = 0;
+static pthread_mutex_t g_prep_mu = PTHREAD_MUTEX_INITIALIZER;
+
+// Makes `kern` launchable with `lds` bytes of dynamic LDS on `device` and, if per_cu != null, returns how many
+// `block`-thread workgroups of it fit a CU.  The caller has made `device` current.
+static hipError_t prepare_kernel(int device, const void *kern, int block, size_t lds, int *per_cu) {
+    pthread_mutex_lock(&g_prep_mu);
+    LaunchPrep *e = nullptr;
+    for (int i = 0; i < g_nprep; ++i)
+        if (g_prep[i].device == device && g_prep[i].kern == kern && g_prep[i].block == block) e = &g_prep[i];
+    if (!e && g_nprep < (int)(sizeof(g_prep) / sizeof(g_prep[0]))) {
+        e = &g_prep[g_nprep++];
+        *e = LaunchPrep{device, kern, block, 0, 0, 0};
+    }
+    LaunchPrep local{device, kern, block, 0, 0, 0};
+    if (!e) e = &local;  // table full: behave as before (per call)
+    hipError_t he = hipSuccess;
+    if (lds > e->lds_max) {
+        he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (he == hipSuccess) e->lds_max = lds;
+    }
+    if (he == hipSuccess && per_cu) {
+        if (e->occ_per_cu == 0 || e->occ_lds != lds) {
+            int n = 0;
+            he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, kern, block, lds);
+            if (he == hipSuccess) {
+                e->occ_per_cu = n < 1 ? 1 : n;
+                e->occ_lds = lds;
+            }
+        }
+        *per_cu = e->occ_per_cu;
+    }
+    pthread_mutex_unlock(&g_prep_mu);
+    return he;
 }
 
 // The kernel instantiation a given env dispatches to (shared by launch and occupancy query).  FULL: the launch has
@@ -455,6 +506,41 @@ int fe_env_render_n(fe_env *env, const int64_t *obs_src, const double *obs_pos, 
     return FE_OK;
 }
 
+int fe_env_check_descriptors(fe_env *env, const int64_t *obs_src, int64_t count, int64_t *first_bad, void *stream) {
+    if (!env || !obs_src || !first_bad || count < 0) return fail(FE_ERR_ARG, "fe_env_check_descriptors: bad argument");
+    *first_bad = -1;
+    if (count == 0) return FE_OK;
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    hipStream_t st = (hipStream_t)stream;
+    unsigned long long *d = nullptr, h[2] = {0ull, (unsigned long long)count};
+    hipError_t he = hipMalloc(&d, sizeof(h));
+    if (he != hipSuccess) return hip_fail(he, "fe_env_check_descriptors: hipMalloc");
+    he = hipMemcpyAsync(d, h, sizeof(h), hipMemcpyHostToDevice, st);
+    if (he == hipSuccess) {
+        const Params &p = env->p;
+        hipLaunchKernelGGL(fe_check_descriptors_kernel, dim3(grid_for(count)), dim3(kBlock), 0, st, obs_src, count,
+                           4 * (int64_t)p.A, (int64_t)p.W, p.D * p.L, d);
+        he = hipGetLastError();
+    }
+    if (he == hipSuccess) he = hipMemcpyAsync(h, d, sizeof(h), hipMemcpyDeviceToHost, st);
+    if (he == hipSuccess) he = hipStreamSynchronize(st);
+    int64_t bad_value = 0;
+    if (he == hipSuccess && h[0] != 0) {
+        he = hipMemcpy(&bad_value, obs_src + h[1], sizeof(int64_t), hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d);
+    if (he != hipSuccess) return hip_fail(he, "fe_env_check_descriptors");
+    if (h[0] != 0) {
+        *first_bad = (int64_t)h[1];
+        return fail(FE_ERR_ARG, "fe_env_check_descriptors: %llu of %lld descriptors lie outside this env's log-return table "
+                    "(first: obs_src[%lld] = %lld; valid: multiples of %d with offset / %d + W <= D*L = %lld, W = %d)",
+                    h[0], (long long)count, (long long)h[1], (long long)bad_value, 4 * env->p.A, 4 * env->p.A,
+                    (long long)(env->p.D * env->p.L), env->p.W);
+    }
+    return FE_OK;
+}
+
 int fe_env_rollout_linear(fe_env *env, const double *weights, double bias, int32_t K, int64_t *obs_src,
                           double *obs_pos, float *actions_out, double *rewards_out, int32_t *dones_out,
                           void *stream) {
@@ -569,7 +655,7 @@ int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, c
     const int block = kBlock;
     if (lds > 160 * 1024)
         return fail(FE_ERR_ARG, "fe_env_rollout_mlp: W1 (%d x %d) does not fit the 160 KiB LDS (%zu bytes needed)", (int)H, 4 * p.W, lds);
-    hipError_t he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t he = prepare_kernel(env->device, kern, block, lds, nullptr);
     if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_mlp: hipFuncSetAttribute");
     void *args[] = {&p, &r};
     he = hipLaunchKernel(kern, dim3((unsigned)grid), dim3(block), args, lds, (hipStream_t)stream);
@@ -608,12 +694,9 @@ static int launch_lstm(fe_env *env, LstmArgs &r, int64_t count, const char *who,
                        (H == 256 ? FE_LSTM_BIG(4) : (H == 512 ? FE_LSTM_BIG(8) : FE_LSTM_BIG(16)))));
 #undef FE_LSTM
 #undef FE_LSTM_BIG
-    hipError_t he = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (he != hipSuccess) return hip_fail(he, "hipFuncSetAttribute (LSTM kernel)");
     int per_cu = 0;
-    he = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kLstmBlock, lds);
-    if (he != hipSuccess) return hip_fail(he, "hipOccupancyMaxActiveBlocksPerMultiprocessor (LSTM kernel)");
-    if (per_cu < 1) per_cu = 1;
+    hipError_t he = prepare_kernel(env->device, kern, kLstmBlock, lds, &per_cu);
+    if (he != hipSuccess) return hip_fail(he, "LSTM kernel: hipFuncSetAttribute / occupancy query");
     const int64_t resident = (int64_t)env->cus * per_cu;  // one pass of resident workgroups, each looping over its tiles
     const int64_t grid = p.num_tiles < resident ? p.num_tiles : resident;
     void *args[] = {&p, &r};
@@ -675,7 +758,7 @@ int fe_env_rollout_lstm_split(fe_env *env, const float *logret_f32, const float 
         return fail(FE_ERR_ARG, "fe_env_rollout_lstm_split: %d sleeves per env x H = %d do not fit the LDS of the accounting launch", (int)p.A, (int)H);
     {
         const void *fk = p.A == 1 ? (const void *)fe_lstm_split_finish_kernel<true> : (const void *)fe_lstm_split_finish_kernel<false>;
-        hipError_t ha = hipFuncSetAttribute(fk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t ha = prepare_kernel(env->device, fk, kBlock, lds, nullptr);
         if (ha != hipSuccess) return hip_fail(ha, "fe_env_rollout_lstm_split: hipFuncSetAttribute");
     }
     const int64_t fgrid = p.num_tiles < 8 * 256 ? p.num_tiles : 8 * 256;
@@ -689,7 +772,7 @@ int fe_env_rollout_lstm_split(fe_env *env, const float *logret_f32, const float 
     const size_t glds = (size_t)(H / 8) * 64 * 16;  // one gate-row tile of weights: H / 8 KiB (128 KiB at H = 1024)
     {
         const void *gk = single ? (const void *)fe_lstm_split_gates_kernel<true> : (const void *)fe_lstm_split_gates_kernel<false>;
-        hipError_t ha = hipFuncSetAttribute(gk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)glds);
+        hipError_t ha = prepare_kernel(env->device, gk, kBlock, glds, nullptr);
         if (ha != hipSuccess) return hip_fail(ha, "fe_env_rollout_lstm_split: hipFuncSetAttribute");
     }
     for (int k = 0; k < K; ++k) {
@@ -703,9 +786,19 @@ int fe_env_rollout_lstm_split(fe_env *env, const float *logret_f32, const float 
             s.t = t;
             if (single) hipLaunchKernelGGL(fe_lstm_split_gates_kernel<true>, ggrid, dim3(kBlock), glds, (hipStream_t)stream, p, s);
             else hipLaunchKernelGGL(fe_lstm_split_gates_kernel<false>, ggrid, dim3(kBlock), glds, (hipStream_t)stream, p, s);
+            // a launch that fails (bad geometry, LDS) fails the first time: stop before queueing W * K launches on
+            // half-written h / c state
+            if (k == 0 && t == 0) {
+                hipError_t hl = hipGetLastError();
+                if (hl != hipSuccess) return hip_fail(hl, "fe_env_rollout_lstm_split: gates launch");
+            }
         }
         if (single) hipLaunchKernelGGL(fe_lstm_split_finish_kernel<true>, dim3((unsigned)fgrid), dim3(kBlock), lds, (hipStream_t)stream, p, s);
         else hipLaunchKernelGGL(fe_lstm_split_finish_kernel<false>, dim3((unsigned)fgrid), dim3(kBlock), lds, (hipStream_t)stream, p, s);
+        if (k == 0) {
+            hipError_t hl = hipGetLastError();
+            if (hl != hipSuccess) return hip_fail(hl, "fe_env_rollout_lstm_split: accounting launch");
+        }
     }
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "fe_env_rollout_lstm_split launch");

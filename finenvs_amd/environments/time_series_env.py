@@ -109,7 +109,7 @@ class TimeSeriesEnv:
             self.set_spaces()
             self.set_environment_params(num_envs, env_indices, obs_buffers)
             if obs_audition > 0 and self.obs_buffers > 0:
-                self._audition_ring(int(obs_audition))
+                self.audition_ring(int(obs_audition))
 
     # ------------------------------------------------------------------ init path
     def _stream(self) -> int:
@@ -267,14 +267,19 @@ class TimeSeriesEnv:
         self._obs_next = 0
         self._step_fn = self._lib.fe_env_step
         self._handle_v = handle.value
+        # bumped by everything that advances the env (step, a fused rollout's run): the fused rollout objects keep their
+        # own observation descriptors and refuse to run on ones that another caller has made stale (rollout.py)
+        self._generation = 0
 
-    def _audition_ring(self, extra: int) -> None:
-        """Ring mode only.  HBM write bandwidth on MI355X depends on where a buffer lies (the same store kernel runs
+    def audition_ring(self, extra: int) -> None:
+        """Ring mode only (also what ``obs_audition=`` runs at construction).  HBM write bandwidth on MI355X depends on where a buffer lies (the same store kernel runs
         5.7 ... 6.5 TB/s on different 20 GB allocations, reproducibly per buffer; tools/placement.hip, DESIGN.md
         section 4), and the step kernel is bound by exactly that.  So: allocate up to ``extra`` more candidate
         buffers than the ring needs (as far as free memory allows), time the observation render into each, keep
         the fastest ``obs_buffers`` and give the rest back.  Values are unaffected; ``self.obs_audition`` records
         what was measured."""
+        if self.obs_buffers < 1:
+            raise ValueError("audition_ring needs ring mode (obs_buffers >= 1)")
         N, W, A = self.num_envs, self.num_intervals, self.num_assets
         nbytes = N * W * 5 * A * (4 if self.obs_dtype == torch.float32 else 8)
         free, _ = torch.cuda.mem_get_info(self._dev)
@@ -397,12 +402,33 @@ class TimeSeriesEnv:
         _lib.check(self._lib.fe_env_describe(self._handle, src.data_ptr(), pos.data_ptr(), self._stream()))
         return src, pos
 
-    def render(self, obs_src: torch.Tensor, obs_pos: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def check_descriptors(self, obs_src: torch.Tensor) -> None:
+        """Debug check for descriptors that did not come from this env object (another rank's gathered chunk, a
+        caller-filled buffer): raises ``FinEnvsNativeError`` naming the first ``obs_src`` whose window does not lie inside
+        this env's log-return table.  The kernels use ``obs_src`` as a raw table offset -- a rank built with another
+        W / D / L, or an uninitialised row, would otherwise end in a GPU memory fault.  Synchronises the stream."""
+        src = obs_src.reshape(-1).to(device=self._dev, dtype=torch.int64).contiguous()
+        first_bad = C.c_int64(-1)
+        if src.numel():
+            _lib.check(self._lib.fe_env_check_descriptors(self._handle, src.data_ptr(), src.numel(), C.byref(first_bad),
+                                                          self._stream()))
+
+    def geometry(self) -> torch.Tensor:
+        """(D, L, W, A) int64 on the host: what two ranks must agree on before one renders the other's descriptors
+        (``TrajectoryBuffer.check_geometry`` exchanges it once)."""
+        D, L, _ = self.price_environments.shape
+        return torch.tensor([D, L, self.num_intervals, self.num_assets], dtype=torch.int64)
+
+    def render(self, obs_src: torch.Tensor, obs_pos: torch.Tensor, out: Optional[torch.Tensor] = None,
+               check: bool = False) -> torch.Tensor:
         """Observations ``(B, W, 5A)`` (this env's ``obs_dtype``) of ANY B descriptors -- e.g. a minibatch drawn from
-        a trajectory of them (PPO_agent.py:175-188 indexes minibatches out of the stored states)."""
+        a trajectory of them (PPO_agent.py:175-188 indexes minibatches out of the stored states).  ``check=True`` runs
+        ``check_descriptors`` first (one host synchronisation: for descriptors of foreign origin)."""
         B, A = int(obs_src.numel()), self.num_assets
         src = obs_src.reshape(B).to(device=self._dev, dtype=torch.int64).contiguous()
         pos = obs_pos.reshape(B, A).to(device=self._dev, dtype=torch.float64).contiguous()
+        if check:
+            self.check_descriptors(src)
         shape = (B, self.num_intervals, 5 * A)
         if out is None:
             out = torch.empty(shape, dtype=self.obs_dtype, device=self._dev)
@@ -471,6 +497,7 @@ class TimeSeriesEnv:
                                             pos.data_ptr() if pos is not None else None, self._stream())
         self._last_descriptors = descriptors_out  # None: the observation just returned was not recorded
         self._stepped = True
+        self._generation += 1
         if rc != 0:
             _lib.check(rc)
         info: Dict = {}

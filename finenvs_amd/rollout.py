@@ -120,6 +120,21 @@ class _FusedEvaluation:
 
         _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
                                                  self.env._stream()))
+        self._seen_generation = self.env._generation
+
+    def _begin_run(self) -> None:
+        """A fused rollout keeps its OWN observation descriptors (what its policy sees next) but reads the account state
+        from the env's shared arrays.  If anything else advanced the env since this object last looked -- ``env.step``,
+        another rollout object's ``run`` -- the two no longer belong together and the policy would act on a stale
+        observation while the accounting uses the current state: refuse instead of running on silently."""
+        if getattr(self, "_seen_generation", None) != self.env._generation:
+            raise RuntimeError("the env was stepped by someone else since this rollout object's last run(): its observation "
+                               "descriptors are stale.  Call sync_from_env() (= look at the state as env.reset() renders it) "
+                               "or drive the env through ONE rollout object.")
+
+    def _end_run(self) -> None:
+        self.env._generation += 1
+        self._seen_generation = self.env._generation
 
     def observation(self) -> torch.Tensor:
         """The (N, W, 5A) observation the next policy evaluation will see."""
@@ -208,6 +223,7 @@ class FusedLinearRollout(_FusedEvaluation):
 
         env, K = self.env, int(num_steps)
         N, A = env.num_envs, env.num_assets
+        self._begin_run()
         actions = torch.empty((K, N, A), dtype=torch.float32, device=env._dev) if record_actions else None
         rewards = torch.empty((K, N), dtype=torch.float64, device=env._dev)
         dones = torch.empty((K, N), dtype=torch.int32, device=env._dev)
@@ -220,6 +236,7 @@ class FusedLinearRollout(_FusedEvaluation):
             _lib.check(env._lib.fe_env_rollout_linear(
                 env._handle, self.weights.data_ptr(), self.bias, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
                 actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
+        self._end_run()
         return actions, rewards, dones
 
 
@@ -280,10 +297,12 @@ class FusedMLPRollout(_FusedEvaluation):
         actions = torch.empty((K, N, A), dtype=torch.float32, device=env._dev) if record_actions else None
         rewards = torch.empty((K, N), dtype=torch.float64, device=env._dev)
         dones = torch.empty((K, N), dtype=torch.int32, device=env._dev)
+        self._begin_run()
         _lib.check(env._lib.fe_env_rollout_mlp(
             env._handle, self._lr32.data_ptr(), self.w1t.data_ptr(), self.wpos.data_ptr(), self.b1.data_ptr(),
             self.w2.data_ptr(), self.b2, self.H, self.act, K, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
             actions.data_ptr() if record_actions else None, rewards.data_ptr(), dones.data_ptr(), env._stream()))
+        self._end_run()
         return actions, rewards, dones
 
 
@@ -371,18 +390,22 @@ class FusedLSTMRollout(_FusedEvaluation):
         self.wout = weight_out.detach().to(dtype=torch.float32, device=dev).reshape(H).contiguous()
         self.bout = float(bias_out)
 
-    def forward(self, obs_src: torch.Tensor, obs_pos: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, obs_src: torch.Tensor, obs_pos: torch.Tensor, out: Optional[torch.Tensor] = None,
+                check: bool = False) -> torch.Tensor:
         """The head evaluated on ANY B observation descriptors (``obs_src (B,)`` int64, ``obs_pos (B, A)`` float64 --
         rows of a ``TrajectoryBuffer(states=True)``, gathered ones included) without stepping the env and without
         materialising the observations: ``(B, A)`` float32.  With ``output_activation="none"`` this is the critic of the
         reference's PPO (finenvs/agents/PPO/critic.py, CriticLSTM): the values of all K + 1 states of a chunk in one
-        launch, e.g. ``critic.forward(traj.obs_src, traj.obs_pos).reshape(K + 1, N)``."""
+        launch, e.g. ``critic.forward(traj.obs_src, traj.obs_pos).reshape(K + 1, N)``.  ``check=True`` validates the
+        descriptors first (``env.check_descriptors``: for descriptors that came from another rank or a caller's buffer)."""
         from . import _lib
 
         env, A = self.env, self.env.num_assets
         B = int(obs_src.numel())
         src = obs_src.reshape(B).to(device=env._dev, dtype=torch.int64).contiguous()
         pos = obs_pos.reshape(B, A).to(device=env._dev, dtype=torch.float64).contiguous()
+        if check:
+            env.check_descriptors(src)
         if out is None:
             out = torch.empty((B, A), dtype=torch.float32, device=env._dev)
         elif out.dtype is not torch.float32 or out.numel() != B * A or not out.is_contiguous() or out.device != env._dev:
@@ -399,7 +422,10 @@ class FusedLSTMRollout(_FusedEvaluation):
 
         Training rollouts (``agent.step`` of finenvs/agents/PPO/PPO_agent.py:98-108): pass ``noise`` -- (K, N, A) f32
         standard-normal draws from the caller's generator -- and ``std = exp(log_standard_deviation)``; the action is
-        ``clamp(mean + std * noise, -1, 1)``, the eval env of a training-mode env acts on the mean.  ``record_means``
+        ``clamp(mean + std * noise, -1, 1)``, the eval env of a training-mode env acts on the mean.  (An evaluate-mode
+        env has no evaluation env, so there every env samples; the reference's ``agent.step`` overwrites the LAST row with
+        the mean whatever the env's mode, PPO_agent.py:104-106 -- a caller who wants that passes ``noise[:, -1] = 0``,
+        which is the same action bit for bit.)  ``record_means``
         keeps the means in ``self.means`` ((K, N, A), what ``log_prob`` needs).  ``trajectory``: an empty
         ``TrajectoryBuffer(K, N, A, states=True)`` without capacity padding -- the kernel writes actions, rewards,
         dones and the K + 1 state descriptors straight into its chunk (``agent.store`` for K steps at once; the
@@ -409,6 +435,7 @@ class FusedLSTMRollout(_FusedEvaluation):
         env, K = self.env, int(num_steps)
         N, A = env.num_envs, env.num_assets
         dev = env._dev
+        self._begin_run()
         src_out = pos_out = None
         if trajectory is not None:
             tr = trajectory
@@ -444,6 +471,7 @@ class FusedLSTMRollout(_FusedEvaluation):
             _lib.check(env._lib.fe_env_rollout_lstm_split(*args, self._workspace.data_ptr(), env._stream()))
         else:
             _lib.check(env._lib.fe_env_rollout_lstm(*args, env._stream()))
+        self._end_run()
         if trajectory is not None:
             trajectory.mark_filled(K)
         return actions, rewards, dones

@@ -251,6 +251,23 @@ class TrajectoryBuffer:
         return ret, adv
 
     # ------------------------------------------------------------------ multi-GPU exchange
+    @staticmethod
+    def check_geometry(env, group=None) -> None:
+        """Once, before the first gather of a ``states=True`` trajectory: every rank's env must have the same table
+        geometry (D, L, W, A), or the descriptors one rank gathers from another are offsets into a table of a different
+        shape -- out-of-bounds reads inside ``env.render`` / ``FusedLSTMRollout.forward``, not an error code.  One tiny
+        all-gather; raises ``ValueError`` on every rank if they differ."""
+        import torch.distributed as dist
+
+        G = dist.get_world_size(group)
+        mine = env.geometry()
+        dev = env._dev if dist.get_backend(group) == "nccl" else torch.device("cpu")
+        out = torch.empty((G, 4), dtype=torch.int64, device=dev)
+        dist.all_gather_into_tensor(out.view(-1), mine.to(dev), group=group)
+        out = out.cpu()
+        if not bool((out == out[0]).all()):
+            raise ValueError(f"ranks disagree on the table geometry (D, L, W, A): {out.tolist()}")
+
     def all_gather(self, group=None, out: Optional[torch.Tensor] = None, with_states: bool = False):
         """One blocking collective: every rank receives every rank's packed chunk.
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define FE_ABI_VERSION 3
+#define FE_ABI_VERSION 4
 #define FE_MAX_ASSETS 256
 
 #define FE_OK 0
@@ -184,6 +184,18 @@ int fe_env_step_traj(fe_env *env, const float *actions, void *obs, double *rewar
 int fe_env_render_n(fe_env *env, const int64_t *obs_src, const double *obs_pos, int64_t count, void *obs, void *stream);
 
 /*
+ * Debug check for descriptors that did not come from THIS env object -- a chunk all-gathered from other ranks
+ * (finenvs_amd/trajectory.py), a caller-filled buffer: fe_env_render_n / fe_lstm_forward / the fused rollouts use
+ * obs_src as an element offset into the log-return table without a range check (a rank built with another W, D or L,
+ * or an uninitialised row, would read out of bounds -- a GPU memory fault, not an error code).  A descriptor is valid
+ * iff  obs_src >= 0,  obs_src % (4*A) == 0  and  obs_src / (4*A) + W <= D*L  (the window lies inside the table; the
+ * reference has no counterpart: its buffer stores the observations themselves, finenvs/agents/PPO/buffer.py:33-56).
+ * Synchronises `stream`.  Returns FE_OK and *first_bad = -1 if all `count` descriptors are valid; FE_ERR_ARG,
+ * *first_bad = index of the first invalid one and fe_last_error() naming its value otherwise.  first_bad: HOST pointer.
+ */
+int fe_env_check_descriptors(fe_env *env, const int64_t *obs_src, int64_t count, int64_t *first_bad, void *stream);
+
+/*
  * Table form of the in-kernel linear policy.  For fixed weights the log-return part of the policy
  * is an indicator of the day's series, like the reference's precomputed log-returns (TSE:179-194):
  * fe_policy_table fills table (D, L, A) f64 with
@@ -238,7 +250,9 @@ int fe_env_rollout_mlp(fe_env *env, const float *logret_f32, const float *w1t, c
  * Training rollouts (finenvs/agents/PPO/PPO_agent.py:98-108, agent.step): with noise (K, N*A) f32 standard-normal
  * draws (made by the caller's generator) and std = exp(log_standard_deviation), the action is
  * clamp(mean + std * noise, -1, 1) (one f32 product, one f32 sum) -- except for the eval env of a training-mode env,
- * which acts on the mean (PPO_agent.py:105-107); means_out (K, N*A) receives the means (for log_prob), and
+ * which acts on the mean (PPO_agent.py:105-107; an evaluate-mode env has no eval env, so all its envs sample -- the
+ * reference's agent.step overwrites its last row with the mean in either mode: pass zero noise for that env, which is
+ * the same action bit for bit); means_out (K, N*A) receives the means (for log_prob), and
  * states_src_out (K+1, N) i64 / states_pos_out (K+1, N*A) f64 the descriptors of the state the policy saw at every
  * step (row k) and of the last returned one (row K) -- the `states` of agent.store (PPO_LSTM_training_SPY.py:27),
  * see fe_env_render_n.  noise / means_out / states_*_out may be NULL.

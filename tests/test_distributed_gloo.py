@@ -155,6 +155,23 @@ def _states_worker(rank, world, port, q, N_TOTAL):
         joined = TrajectoryBuffer.join_shards(src_g, N_TOTAL)
         ok &= tuple(joined.shape) == (T + 1, N_TOTAL)
         # the blocking form carries the states too (the chunk being filled: only its carried row 0 is set so far)
+        # geometry handshake before anyone renders a foreign descriptor: equal on all ranks passes, one odd rank raises
+        # on EVERY rank (it is a collective, so nobody is left waiting)
+        class _Env:
+            _dev = torch.device("cpu")
+
+            def __init__(self, W):
+                self.W = W
+
+            def geometry(self):
+                return torch.tensor([64, 518, self.W, A], dtype=torch.int64)
+
+        TrajectoryBuffer.check_geometry(_Env(128))
+        try:
+            TrajectoryBuffer.check_geometry(_Env(128 if rank else 64))
+            ok = False
+        except ValueError as exc:
+            ok &= "geometry" in str(exc)
         a_b, r_b, d_b, src_b, pos_b, packed_b = buf.all_gather(with_states=True)
         ok &= tuple(src_b.shape) == (world, T + 1, CAP) and tuple(packed_b.shape) == (world, buf._nbytes)
         ok &= torch.equal(src_b[rank, 0, :n], buf.obs_src[0])

@@ -458,6 +458,9 @@ def test_lstm_forward_on_descriptors_is_the_critic_without_observations(fe, fo, 
     assert torch.equal(mb, values.reshape(-1, A)[idx])
     assert critic.forward(traj.obs_src[:0], traj.obs_pos[:0]).shape == (0, A)
     from finenvs_amd._lib import FinEnvsNativeError
+    with pytest.raises(RuntimeError, match="stale"):
+        critic.run(1)  # `roll` advanced the env: the critic object's own descriptors are behind (forward() takes its descriptors as arguments)
+    critic.sync_from_env()
     with pytest.raises(FinEnvsNativeError, match="out_activation"):
         critic.run(1)  # an action needs bounds: "none" is for forward() only
 

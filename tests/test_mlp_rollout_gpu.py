@@ -180,6 +180,35 @@ def test_mlp_rollout_argument_errors(fe, fo):
         roll.run(1)
 
 
+def test_fused_rollouts_refuse_stale_descriptors(fe, fo):
+    """A fused rollout object keeps its own observation descriptors; the account state lives in the env.  Stepping the
+    env behind its back (env.step, another rollout object) leaves the descriptors one observation behind: run() must
+    refuse until sync_from_env() is called, and then equal a fresh rollout object on the same state."""
+    from finenvs_amd.rollout import FusedLinearRollout, FusedMLPRollout
+
+    ref, env = _make(fe, fo, 40, 1, 8, 5, 40, 0.0, False, seed=1)
+    W1, b1, W2, b2 = _weights(8, 32, seed=1)
+    mlp = FusedMLPRollout(env, torch.from_numpy(W1), torch.from_numpy(b1), torch.from_numpy(W2), b2, activation="relu")
+    lin = FusedLinearRollout(env, torch.ones((8, 5), dtype=torch.float64) * 0.1, 0.0)
+    mlp.run(2)
+    mlp.run(1)  # its own runs keep it fresh
+    with pytest.raises(RuntimeError, match="stale"):
+        lin.run(1)  # built before mlp advanced the env
+    env.step(torch.zeros((40, 1), device=env.device))
+    with pytest.raises(RuntimeError, match="stale"):
+        mlp.run(1)
+    mlp.sync_from_env()
+    state = (env.cash, env.margin, env.long_shares, env.short_shares, env._spot0, env.env_indices, env._counters)
+    saved = [t.clone() for t in state]
+    a1, r1, d1 = mlp.run(3)
+    # replay from the same state with a rollout object created there
+    for dst, src in zip(state, saved):
+        dst.copy_(src)
+    fresh = FusedMLPRollout(env, torch.from_numpy(W1), torch.from_numpy(b1), torch.from_numpy(W2), b2, activation="relu")
+    a2, r2, d2 = fresh.run(3)
+    assert torch.equal(a1, a2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+
+
 def test_mlp_evaluation_loop_returns_match_stepwise_oracle(fe, fo):
     """FusedMLPRollout.evaluate_returns = the reference's evaluation loop (PPO_LSTM_testing_SPY.py:43-52) with an MLP
     actor, K steps per launch: the per-env episode returns equal the oracle stepped one action at a time (ReLU head:

@@ -221,3 +221,32 @@ def test_graphed_evaluation_loop_with_a_torch_lstm_actor(fe, fo):
     got = roll.evaluate_returns()
     assert torch.equal(got, want)
     assert float(got.abs().sum()) > 0
+
+
+def test_foreign_descriptors_can_be_checked_before_they_are_rendered(fe, fo):
+    """obs_src is a raw offset into the log-return table: the kernels do not range-check it.  For descriptors that
+    did not come from this env object (another rank's gathered chunk, an uninitialised caller buffer) the debug check
+    names the first bad one instead of letting the render fault."""
+    from finenvs_amd._lib import FinEnvsNativeError
+
+    _, env = _make(fe, fo, 50, 2, 8, 5, 40, 0.0, seed=2)
+    D, L, _ = env.price_environments.shape
+    src, pos = env.describe()
+    env.check_descriptors(src)                      # its own descriptors are fine
+    obs = env.render(src, pos, check=True)
+    assert torch.equal(obs, env.reset())
+    last_valid = torch.tensor([(D * L - 8) * 8], dtype=torch.int64, device="cuda")  # the last window of the last day
+    env.check_descriptors(last_valid)
+    for bad_value, why in ((-8, "negative"), (12, "not a row start"), ((D * L - 7) * 8, "window past the table"),
+                           (1 << 40, "garbage")):
+        bad = src.clone()
+        bad[17] = bad_value
+        with pytest.raises(FinEnvsNativeError, match=r"obs_src\[17\]"):
+            env.check_descriptors(bad)
+        with pytest.raises(FinEnvsNativeError, match="descriptors lie outside"):
+            env.render(bad, pos, check=True)
+    two = src.clone()
+    two[40], two[3] = -1, -1
+    with pytest.raises(FinEnvsNativeError, match=r"2 of 50 .*obs_src\[3\]"):
+        env.check_descriptors(two)
+    assert [int(x) for x in env.geometry()] == [D, L, 8, 2]
