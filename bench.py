@@ -138,6 +138,14 @@ _LIVE_PMC_BROKEN = []  # first failure of a live counter pass: later workloads f
 _PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_", "ROCTX_")
 
 
+def is_step_kernel(name: str) -> bool:
+    """fe_env_kernel<OT, VEC, SINGLE, RESET_ONLY, FULL> with RESET_ONLY = false (either form of the step; the reset()
+    renderer is the same template with RESET_ONLY = true)."""
+    import re
+
+    return re.search(r"fe_env_kernel<[^>]*, (?:true|false), false, (?:true|false)>", name) is not None
+
+
 def under_profiler(environ=None) -> bool:
     """True when THIS process already runs under rocprofv3 / a rocprofiler tool library.  A nested
     `rocprofv3 --pmc` would inherit the preloaded tool library: it initialises the GPU in the child launcher, which
@@ -201,7 +209,7 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str, no_audition: bool = Fa
             rows = []
             for f in glob.glob(os.path.join(out, kind, "*", "*_counter_collection.csv")):
                 for row in csv.DictReader(open(f)):
-                    if "fe_env_kernel" in row["Kernel_Name"] and ", false>" in row["Kernel_Name"] and row["Counter_Name"] == kind:
+                    if is_step_kernel(row["Kernel_Name"]) and row["Counter_Name"] == kind:
                         rows.append(float(row["Counter_Value"]))
             if len(rows) < 8:
                 return None, f"no {kind} rows for the step kernel"

@@ -44,7 +44,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-VARIANT_KNOBS = ("FE_HOIST_FIRST", "FE_F32_WAVES", "FE_STAMP", "FE_X")  # live tunables of fe_device_common.h (+ the temporary stamp build)
+VARIANT_KNOBS = ("FE_HOIST_FIRST", "FE_F32_WAVES")  # the live tunables of fe_device_common.h
 
 
 def build_variant(tag: str, defines: dict, verbose: bool = False) -> str:

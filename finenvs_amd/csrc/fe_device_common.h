@@ -40,15 +40,6 @@ constexpr int kStoreAuxMulti = 2;
 #ifndef FE_F32_WAVES
 #define FE_F32_WAVES 6
 #endif
-// TEMPORARY diagnostic build (removed again after the round-3 start-up measurements, tools/stamp_step.py): every
-// workgroup of the single-asset step kernel writes s_memrealtime stamps (100 MHz) into the buffer bound as
-// fe_env_bind_stats' eval_return argument (grid * 8 u64; the statistics themselves are off in this build).
-#ifndef FE_STAMP
-#define FE_STAMP 0
-#endif
-#ifndef FE_X   /* TEMPORARY round-3 A/B bit: 2 = always the FULL step kernel */
-#define FE_X 0
-#endif
 template <typename OT>
 constexpr bool kHoistFirst = FE_HOIST_FIRST != 0 && (sizeof(OT) == 8 || FE_F32_WAVES <= 5);
 

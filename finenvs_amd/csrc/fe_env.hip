@@ -194,7 +194,7 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     const bool f32 = env->cfg.obs_is_f32 != 0, single = p.A == 1;
-    const bool full = !RESET_ONLY && ((FE_X & 2) || p.evaluate || p.run_ret || desc_src || act_store);
+    const bool full = !RESET_ONLY && (p.evaluate || p.run_ret || desc_src || act_store);
     const void *kern = RESET_ONLY ? kernel_for<true, false>(f32, env->vec, single)
                                   : (full ? kernel_for<false, true>(f32, env->vec, single) : kernel_for<false, false>(f32, env->vec, single));
     hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, env->lds, st);
@@ -419,15 +419,9 @@ int fe_env_bind_stats(fe_env *env, float *running_returns, double *accumulators,
         return FE_OK;
     }
     if (!accumulators || !eval_return) return fail(FE_ERR_ARG, "fe_env_bind_stats: null accumulator pointer");
-#if FE_STAMP
-    env->p.run_ret = nullptr;  // statistics off; eval_return carries the stamp buffer
-    env->p.stat_acc = nullptr;
-    env->p.stat_eval = eval_return;
-#else
     env->p.run_ret = running_returns;
     env->p.stat_acc = accumulators;
     env->p.stat_eval = eval_return;
-#endif
     return FE_OK;
 }
 

@@ -302,7 +302,6 @@ struct PipeState {
     float action_cur, action_nxt, action_nn;  // actions run TWO tiles ahead: a caller's action buffer may be cold (a new
                                               // trajectory slot every step costs a TLB walk + an HBM round trip, ~5 us)
     int64_t idx1, spot1, idx2, spot2;
-    unsigned long long t_accounted;  // FE_STAMP builds
 };
 
 // env number of lane e in tile t, and whether that lane has an env there
@@ -333,9 +332,6 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
         account_core<true, FULL>(p, l, 1, e, 0, act0, n_cur, n_cur, ps.in_cur, ps.action_cur, p.rew, p.done);
     }
     lds_barrier();
-#if FE_STAMP
-    if (FIRST) ps.t_accounted = __builtin_amdgcn_s_memrealtime();
-#endif
     // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
     bool act1, act2;
     const int64_t n_nxt = pipe_env_of(p, EB, e, tile_at(p, k + 1), act1);
@@ -369,10 +365,6 @@ constexpr int kEnvKernelWaves = !SINGLE ? kMultiAssetWaves
 template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY, bool FULL>
 __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONLY>)) void fe_env_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
-#if FE_STAMP
-    const unsigned long long t_entry = __builtin_amdgcn_s_memrealtime();  // before any kernel argument is needed
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
     const TileLds l = carve_lds(smem + 4 * kStageBytes, EB, EB * A);
@@ -412,13 +404,6 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
         // i+2 are already in flight, so only the very first tile pays phase 1's two dependent
         // memory round trips.
         int64_t tile = tile_at(p, 0);
-#if FE_STAMP
-        unsigned long long *stamps = reinterpret_cast<unsigned long long *>(p.stat_eval);
-        if (stamps && tid == 0) {
-            stamps[blockIdx.x * 8 + 0] = __builtin_amdgcn_s_memrealtime();
-            stamps[blockIdx.x * 8 + 6] = t_entry;
-        }
-#endif
         PipeState ps;
         ps.action_cur = 0.0f; ps.action_nxt = 0.0f; ps.action_nn = 0.0f;
         bool act0, act1;
@@ -431,10 +416,6 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
         if (act0) ps.action_cur = p.actions[n_cur];
         if constexpr (kActionsTwoAhead<OT>)
             if (act1) ps.action_nxt = p.actions[n_nxt];  // the second tile's action leaves with the first one's
-#if FE_STAMP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (stamps && tid == 0) stamps[blockIdx.x * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-#endif
         load_bar(p, 1, 0, act0, ps.idx1, ps.spot1, ps.in_cur);
         PreTuples<OT> pre{};  // table tuples of this wavefront's first phase-2 iteration (FE_HOIST_FIRST)
         // Start-up chain of the first tile: the window descriptors need the index loads only, so they are published
@@ -460,29 +441,13 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
                 }
             }
         }
-#if FE_STAMP
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (stamps && tid == 0) stamps[blockIdx.x * 8 + 5] = __builtin_amdgcn_s_memrealtime();
-#endif
         load_head(p, act1, n_nxt, ps.idx1, ps.spot1);
         // one tile per call; the workgroup's first tile is peeled (FIRST) so that `pre` dies before the loop
         if (tile < p.num_tiles) {
             single_tile<OT, VEC, true, FULL>(p, l, stage, ps, tile, 0, EB, e, lane, wave, pre);
-#if FE_STAMP
-            if (stamps && tid == 0) {
-                stamps[blockIdx.x * 8 + 1] = ps.t_accounted;
-                stamps[blockIdx.x * 8 + 2] = __builtin_amdgcn_s_memrealtime();
-            }
-#endif
             for (int64_t k = 1; (tile = tile_at(p, k)) < p.num_tiles; ++k)
                 single_tile<OT, VEC, false, FULL>(p, l, stage, ps, tile, k, EB, e, lane, wave, PreTuples<OT>{});
         }
-#if FE_STAMP
-        if (stamps && tid == 0) {
-            __builtin_amdgcn_s_waitcnt(0);  // this wavefront's stores have left
-            stamps[blockIdx.x * 8 + 3] = __builtin_amdgcn_s_memrealtime();
-        }
-#endif
     }
 }
 

@@ -13,11 +13,11 @@ for set in "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
   rocprofv3 --pmc $set --output-format csv -d $OUT/p$i -- python3 bench.py --config $CFG --steps 8 --warmup 4 --no-cpu --no-extra --no-pmc --repeats 2 > $OUT/b$i.json 2> $OUT/e$i.err || echo "pass $i failed"
 done
 python3 - <<PY
-import csv, glob, collections
+import csv, glob, collections, re
 agg = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if "fe_env_kernel" in r["Kernel_Name"] and ", false>" in r["Kernel_Name"]:  # the step kernel (RESET_ONLY = false)
+        if re.search(r"fe_env_kernel<[^>]*, (?:true|false), false, (?:true|false)>", r["Kernel_Name"]):  # the step kernel (RESET_ONLY = false)
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print(f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
