@@ -139,11 +139,11 @@ _PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_", "ROC
 
 
 def is_step_kernel(name: str) -> bool:
-    """fe_env_kernel<OT, VEC, SINGLE, RESET_ONLY, FULL> with RESET_ONLY = false (either form of the step; the reset()
+    """fe_env_kernel<OT, VEC, SINGLE, RESET_ONLY, FORM> with RESET_ONLY = false (any form of the step; the reset()
     renderer is the same template with RESET_ONLY = true)."""
     import re
 
-    return re.search(r"fe_env_kernel<[^>]*, (?:true|false), false, (?:true|false)>", name) is not None
+    return re.search(r"fe_env_kernel<[^>]*, (?:true|false), false, \d+>", name) is not None
 
 
 def under_profiler(environ=None) -> bool:

@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfinenvs_amd.so")
 
 FE_ABI_VERSION = 4
+FE_OK, FE_ERR_ARG, FE_ERR_HIP, FE_ERR_STATE = 0, -1, -2, -3
 FE_MAX_ASSETS = 256
 
 
@@ -45,6 +46,9 @@ SIGNATURES = {
     "fe_env_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_env_describe": (C.c_int, [_vp, _vp, _vp, _vp]),
     "fe_env_render": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "fe_env_step_notify": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
+    "fe_host_flag_create": (C.c_int, [C.POINTER(_vp)]),
+    "fe_host_flag_destroy": (C.c_int, [_vp]),
     "fe_env_render_n": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),
     "fe_env_check_descriptors": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64), _vp]),
     "fe_env_step_traj": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

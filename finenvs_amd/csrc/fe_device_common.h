@@ -102,6 +102,8 @@ struct Params {
     int64_t *desc_src;   // optional (fe_env_step_traj): descriptors of the observation this step returns
     double *desc_pos;
     float *act_store;    // optional (fe_env_step_traj): the actions, copied into a trajectory slot
+    unsigned long long *host_flag;  // optional (fe_env_step_notify): host memory that learns early whether the eval env finished
+    unsigned long long flag_seq;
     int64_t N, D, L;
     int64_t num_tiles;
     int64_t eval_env;

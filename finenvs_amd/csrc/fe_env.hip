@@ -165,13 +165,13 @@ static hipError_t prepare_kernel(int device, const void *kern, int block, size_t
     return he;
 }
 
-// The kernel instantiation a given env dispatches to (shared by launch and occupancy query).  FULL: the launch has
-// optional outputs (evaluate-mode bookkeeping, episode statistics, trajectory descriptors / action copy); the lean
-// form is the same kernel without them (same launch bounds, same LDS).
-template <bool RESET_ONLY, bool FULL>
+// The kernel instantiation a given env dispatches to (shared by launch and occupancy query).  FORM (fe_step_kernel.h):
+// kFull = the launch has optional outputs (evaluate-mode bookkeeping, episode statistics, trajectory descriptors /
+// action copy), kLean = none of them, kNotify = lean + the host flag of fe_env_step_notify; same launch bounds, same LDS.
+template <bool RESET_ONLY, int FORM>
 static const void *kernel_for(bool f32, int vec, bool single) {
 #define FE_PICK(OT, VEC) \
-    (single ? (const void *)fe_env_kernel<OT, VEC, true, RESET_ONLY, FULL> : (const void *)fe_env_kernel<OT, VEC, false, RESET_ONLY, FULL>)
+    (single ? (const void *)fe_env_kernel<OT, VEC, true, RESET_ONLY, FORM> : (const void *)fe_env_kernel<OT, VEC, false, RESET_ONLY, FORM>)
     if (f32) return vec == 4 ? FE_PICK(float, 4) : (vec == 2 ? FE_PICK(float, 2) : FE_PICK(float, 1));
     return vec == 2 ? FE_PICK(double, 2) : FE_PICK(double, 1);
 #undef FE_PICK
@@ -181,7 +181,8 @@ static const void *kernel_for(bool f32, int vec, bool single) {
 // modified by reset/step, so concurrent calls on different streams do not race on the host side.
 template <bool RESET_ONLY>
 static int launch_env(const fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
-                      hipStream_t st, int64_t *desc_src = nullptr, double *desc_pos = nullptr, float *act_store = nullptr) {
+                      hipStream_t st, int64_t *desc_src = nullptr, double *desc_pos = nullptr, float *act_store = nullptr,
+                      uint64_t *host_flag = nullptr, uint64_t flag_seq = 0) {
     Params p = env->p;
     p.actions = actions;
     p.obs = obs;
@@ -190,13 +191,18 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     p.desc_src = desc_src;
     p.desc_pos = desc_pos;
     p.act_store = act_store;
+    p.host_flag = reinterpret_cast<unsigned long long *>(host_flag);
+    p.flag_seq = flag_seq;
     void *args[] = {&p};
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     const bool f32 = env->cfg.obs_is_f32 != 0, single = p.A == 1;
     const bool full = !RESET_ONLY && (p.evaluate || p.run_ret || desc_src || act_store);
-    const void *kern = RESET_ONLY ? kernel_for<true, false>(f32, env->vec, single)
-                                  : (full ? kernel_for<false, true>(f32, env->vec, single) : kernel_for<false, false>(f32, env->vec, single));
+    if (host_flag && full)
+        return fail(FE_ERR_STATE, "fe_env_step_notify: not together with evaluate mode, bound episode statistics or trajectory outputs");
+    const void *kern = RESET_ONLY ? kernel_for<true, kLean>(f32, env->vec, single)
+                       : (host_flag ? kernel_for<false, kNotify>(f32, env->vec, single)
+                                    : (full ? kernel_for<false, kFull>(f32, env->vec, single) : kernel_for<false, kLean>(f32, env->vec, single)));
     hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, env->lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");
     return FE_OK;
@@ -206,7 +212,7 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
 static int configure_launch(fe_env *env) {
     const fe_config &cfg = env->cfg;
     const int A = cfg.A;
-    const void *kern = kernel_for<false, true>(cfg.obs_is_f32 != 0, env->vec, A == 1);
+    const void *kern = kernel_for<false, kFull>(cfg.obs_is_f32 != 0, env->vec, A == 1);
     // How many workgroups the chip holds at once for this kernel variant (registers + LDS).
     int64_t cap = kBlock / A > 0 ? kBlock / A : 1;  // one sleeve per lane in phase 1
     int per_cu = 0;
@@ -435,6 +441,31 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
     if (!env || !actions || !obs || !rewards || !dones) return fail(FE_ERR_ARG, "fe_env_step: null argument");
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step: state not bound");
     return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream);
+}
+
+int fe_env_step_notify(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                       uint64_t *host_flag, uint64_t seq, void *stream) {
+    if (!env || !actions || !obs || !rewards || !dones || !host_flag) return fail(FE_ERR_ARG, "fe_env_step_notify: null argument");
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step_notify: state not bound");
+    if (env->p.eval_env < 0)
+        return fail(FE_ERR_ARG, "fe_env_step_notify: this env has no evaluation env (evaluate mode, or a shard without it)");
+    return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream, nullptr, nullptr, nullptr, host_flag, seq);
+}
+
+int fe_host_flag_create(uint64_t **host_flag) {
+    if (!host_flag) return fail(FE_ERR_ARG, "fe_host_flag_create: null argument");
+    void *ptr = nullptr;
+    // mapped into the device's address space, coherent (fine-grained): a device store is visible to a polling host thread
+    hipError_t he = hipHostMalloc(&ptr, sizeof(uint64_t), hipHostMallocMapped | hipHostMallocCoherent | hipHostMallocPortable);
+    if (he != hipSuccess) return hip_fail(he, "fe_host_flag_create: hipHostMalloc");
+    *reinterpret_cast<volatile uint64_t *>(ptr) = 0;
+    *host_flag = reinterpret_cast<uint64_t *>(ptr);
+    return FE_OK;
+}
+
+int fe_host_flag_destroy(uint64_t *host_flag) {
+    if (host_flag) (void)hipHostFree(host_flag);
+    return FE_OK;
 }
 
 int fe_env_step_traj(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,

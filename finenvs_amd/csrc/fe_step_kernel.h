@@ -8,9 +8,11 @@ namespace {
 // (it holds barriers).  On return l.src / l.pos describe the observation of this step (terminal
 // window on done steps, exactly what step() returns, TSE:321) and the state arrays hold the
 // post-step (post-reset) state.
-// FULL = false is the lean form for launches that have none of the optional outputs (evaluate-mode bookkeeping,
-// episode statistics, trajectory descriptors / action copy): their eight pointers never become live scalars.
-template <bool SINGLE, bool FULL>
+// FORM: kLean = launches that have none of the optional outputs (evaluate-mode bookkeeping, episode statistics,
+// trajectory descriptors / action copy): their eight pointers never become live scalars; kFull = all of them;
+// kNotify = the lean form + fe_env_step_notify's host flag (and its last-tile-first walk).
+constexpr int kLean = 0, kFull = 1, kNotify = 2;
+template <bool SINGLE, int FORM>
 __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, int A, int e, int a, bool active,
                                              int64_t n, int64_t sl, const SleeveIn &in, float action,
                                              double *rew_out, int32_t *done_out) {
@@ -41,7 +43,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             const int64_t s0c = s0 + W <= L ? s0 : L - W;
             l.src[e] = (in.idx * L + s0c) * rs;
         }
-        if constexpr (FULL) {
+        if constexpr (FORM == kFull) {
             if (p.desc_src) {  // the returned observation as descriptors, 8 + 8A bytes per env (a trajectory's `states`)
                 p.desc_pos[sl] = s.pos_obs;
                 if (a == 0) p.desc_src[n] = l.src[e];
@@ -77,7 +79,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             }
         }
         p.spot0[n] = s0;
-        if constexpr (FULL) {
+        if constexpr (FORM == kFull) {
             if (p.evaluate) {  // TSE:523-536
                 const bool term = p.terminated[n] != 0;
                 if (term) rew = 0.0;
@@ -90,7 +92,13 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
         }
         rew_out[n] = rew;
         done_out[n] = any ? 1 : 0;
-        if constexpr (FULL) {
+        if constexpr (FORM == kNotify) {
+            // fe_env_step_notify: the host polls this instead of copying dones back after the launch (TSE:510); a relaxed
+            // system-scope store -- the host reads nothing else of this launch through it
+            if (n == p.eval_env)
+                __hip_atomic_store(p.host_flag, (p.flag_seq << 1) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if constexpr (FORM == kFull) {
             if (p.run_ret) {  // PPO_agent.py:120-132 without its per-step host sync
                 float cr = (float)((double)p.run_ret[n] + rew);
                 if (any) {
@@ -121,7 +129,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
 }
 
 // unpipelined form: load, then account
-template <bool SINGLE, bool FULL>
+template <bool SINGLE, int FORM>
 __device__ __forceinline__ void account_tile(const Params &p, const TileLds &l, int A, int e, int a, bool active,
                                              int64_t n, int64_t sl, float action, double *rew_out,
                                              int32_t *done_out) {
@@ -129,7 +137,7 @@ __device__ __forceinline__ void account_tile(const Params &p, const TileLds &l, 
     SleeveIn in;
     load_head(p, active, n, idx, spot);
     load_body(p, A, a, active, sl, idx, spot, in);
-    account_core<SINGLE, FULL>(p, l, A, e, a, active, n, sl, in, action, rew_out, done_out);
+    account_core<SINGLE, FORM>(p, l, A, e, a, active, n, sl, in, action, rew_out, done_out);
 }
 
 // reset(): the observation descriptors of the CURRENT state (TSE:423-435); changes no state.
@@ -289,9 +297,12 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
 // The k-th tile of this workgroup, or p.num_tiles when it has none left: grid-strided (tile t -> workgroup t % grid;
 // the grid is a multiple of 8, so t % 8 -- the XCD -- is stable per workgroup and envs mapped n mod D keep each XCD's
 // L2 on the same days).  XCD-blocked and scrambled orders were measured slower (profiles/r02_microbench/ab_xcd_blocked.txt).
-__device__ __forceinline__ int64_t tile_at(const Params &p, int64_t k) {
+// `last_first` (fe_env_step_notify): the same walk from the other end, so that the tile holding the evaluation env --
+// the last env -- is the first tile of workgroup 0.
+__device__ __forceinline__ int64_t tile_at(const Params &p, int64_t k, bool last_first = false) {
     const int64_t t = blockIdx.x + k * (int64_t)gridDim.x;
-    return t < p.num_tiles ? t : p.num_tiles;
+    if (t >= p.num_tiles) return p.num_tiles;
+    return last_first ? p.num_tiles - 1 - t : t;
 }
 
 // Software pipeline state of the single-asset step kernel: inputs of the current tile, prefetched inputs of the
@@ -321,7 +332,7 @@ constexpr bool kActionsTwoAhead = sizeof(OT) == 8;
 // One tile of the single-asset pipeline: account it (inputs already in registers), prefetch the next tile's body and
 // the head of the one after, stream its observation.  FIRST: the workgroup's first tile, whose first phase-2
 // iteration may use table tuples loaded before the accounting (`pre`).
-template <typename OT, int VEC, bool FIRST, bool FULL>
+template <typename OT, int VEC, bool FIRST, int FORM>
 __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, OT *stage, PipeState &ps, int64_t tile,
                                             int64_t k, int EB, int e, int lane, int wave, PreTuples<OT> pre) {
     const int64_t n0 = tile * EB;
@@ -329,13 +340,14 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
     {
         bool act0;
         const int64_t n_cur = pipe_env_of(p, EB, e, tile, act0);
-        account_core<true, FULL>(p, l, 1, e, 0, act0, n_cur, n_cur, ps.in_cur, ps.action_cur, p.rew, p.done);
+        account_core<true, FORM>(p, l, 1, e, 0, act0, n_cur, n_cur, ps.in_cur, ps.action_cur, p.rew, p.done);
     }
     lds_barrier();
     // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
     bool act1, act2;
-    const int64_t n_nxt = pipe_env_of(p, EB, e, tile_at(p, k + 1), act1);
-    const int64_t n_nn = pipe_env_of(p, EB, e, tile_at(p, k + 2), act2);
+    constexpr bool rev = FORM == kNotify;
+    const int64_t n_nxt = pipe_env_of(p, EB, e, tile_at(p, k + 1, rev), act1);
+    const int64_t n_nn = pipe_env_of(p, EB, e, tile_at(p, k + 2, rev), act2);
     load_body(p, 1, 0, act1, n_nxt, ps.idx1, ps.spot1, ps.in_nxt);
     if constexpr (!kActionsTwoAhead<OT>)
         if (act1) ps.action_nxt = p.actions[n_nxt];
@@ -362,7 +374,7 @@ template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY>
 constexpr int kEnvKernelWaves = !SINGLE ? kMultiAssetWaves
                                 : (RESET_ONLY ? kRenderWaves
                                               : (sizeof(OT) == 8 ? (kHoistFirst<OT> ? 4 : kRenderWaves) : kF32StepWaves<OT, VEC>));
-template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY, bool FULL>
+template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY, int FORM>
 __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONLY>)) void fe_env_kernel(const Params p) {
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
@@ -387,13 +399,14 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
         }
     } else if constexpr (!SINGLE) {
         // multi-asset tiles stream hundreds of KiB each: phase 1 is <1 % of a tile, no pipelining needed
-        for (int64_t k = 0, tile; (tile = tile_at(p, k)) < p.num_tiles; ++k) {
+        constexpr bool rev = FORM == kNotify;
+        for (int64_t k = 0, tile; (tile = tile_at(p, k, rev)) < p.num_tiles; ++k) {
             const int64_t n0 = tile * EB;
             const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
             const bool active = e < ebt;
             const int64_t n = n0 + e;
             const int64_t sl = n * A + a;
-            account_tile<SINGLE, FULL>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
+            account_tile<SINGLE, FORM>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
             stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
                                          reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
             lds_barrier();  // LDS is reused by the next tile
@@ -403,12 +416,13 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
         // (phase 2, the long part), the state + bar gathers of tile i+1 and the index loads of tile
         // i+2 are already in flight, so only the very first tile pays phase 1's two dependent
         // memory round trips.
-        int64_t tile = tile_at(p, 0);
+        constexpr bool rev = FORM == kNotify;
+        int64_t tile = tile_at(p, 0, rev);
         PipeState ps;
         ps.action_cur = 0.0f; ps.action_nxt = 0.0f; ps.action_nn = 0.0f;
         bool act0, act1;
         const int64_t n_cur = pipe_env_of(p, EB, e, tile, act0);
-        const int64_t n_nxt = pipe_env_of(p, EB, e, tile_at(p, 1), act1);
+        const int64_t n_nxt = pipe_env_of(p, EB, e, tile_at(p, 1, rev), act1);
         // first tile: everything that needs no index goes out with the index loads (one round trip), only the
         // bar gather (an L2 hit) waits for them
         load_head(p, act0, n_cur, ps.idx1, ps.spot1);
@@ -444,9 +458,9 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
         load_head(p, act1, n_nxt, ps.idx1, ps.spot1);
         // one tile per call; the workgroup's first tile is peeled (FIRST) so that `pre` dies before the loop
         if (tile < p.num_tiles) {
-            single_tile<OT, VEC, true, FULL>(p, l, stage, ps, tile, 0, EB, e, lane, wave, pre);
-            for (int64_t k = 1; (tile = tile_at(p, k)) < p.num_tiles; ++k)
-                single_tile<OT, VEC, false, FULL>(p, l, stage, ps, tile, k, EB, e, lane, wave, PreTuples<OT>{});
+            single_tile<OT, VEC, true, FORM>(p, l, stage, ps, tile, 0, EB, e, lane, wave, pre);
+            for (int64_t k = 1; (tile = tile_at(p, k, rev)) < p.num_tiles; ++k)
+                single_tile<OT, VEC, false, FORM>(p, l, stage, ps, tile, k, EB, e, lane, wave, PreTuples<OT>{});
         }
     }
 }

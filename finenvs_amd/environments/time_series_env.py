@@ -267,6 +267,16 @@ class TimeSeriesEnv:
         self._obs_next = 0
         self._step_fn = self._lib.fe_env_step
         self._handle_v = handle.value
+        # redraw="torch" with an evaluation env: the per-step host read of its done flag (TSE:510) goes through a
+        # coherent host flag the kernel writes as soon as that env is accounted (fe_env_step_notify), not through a
+        # device-to-host copy after the launch
+        self._flag = None
+        self._flag_seq = 0
+        if self.redraw == "torch" and self._eval_env >= 0:
+            flag = C.c_void_p()
+            _lib.check(self._lib.fe_host_flag_create(C.byref(flag)))
+            self._flag = flag
+            self._flag_word = C.c_uint64.from_address(flag.value)
         # bumped by everything that advances the env (step, a fused rollout's run): the fused rollout objects keep their
         # own observation descriptors and refuse to run on ones that another caller has made stale (rollout.py)
         self._generation = 0
@@ -338,8 +348,35 @@ class TimeSeriesEnv:
     def __del__(self):
         h = getattr(self, "_handle", None)
         if h is not None and getattr(self, "_lib", None) is not None:
+            if getattr(self, "_flag", None) is not None:
+                try:  # the last launch may still be about to write the flag
+                    torch.cuda.synchronize(self._dev)
+                except Exception:  # noqa: BLE001  (interpreter shutdown)
+                    pass
+                self._lib.fe_host_flag_destroy(self._flag)
+                self._flag = None
             self._lib.fe_env_destroy(h)
             self._handle = None
+
+    def _eval_env_done(self, seq: int) -> bool:
+        """Poll the host flag of fe_env_step_notify until it carries this step's sequence number; its low bit is the
+        evaluation env's done flag (TSE:510).  The kernel writes it a few microseconds after it starts."""
+        import time
+
+        word = self._flag_word
+        v = word.value
+        if (v >> 1) != seq:
+            t0 = time.monotonic()
+            spins = 0
+            while True:
+                v = word.value
+                if (v >> 1) == seq:
+                    break
+                spins += 1
+                if spins & 0xFFF == 0 and time.monotonic() - t0 > 60.0:
+                    torch.cuda.synchronize(self._dev)  # surfaces a launch / kernel error if there was one
+                    raise RuntimeError("the step kernel never reported the evaluation env's done flag")
+        return bool(v & 1)
 
     # ------------------------------------------------------------------ reference-compatible views
     @property
@@ -478,7 +515,13 @@ class TimeSeriesEnv:
             dones = dones_out
             if dones.dtype is not torch.int32 or dones.numel() != N or not dones.is_contiguous() or dones.device != self._dev:
                 raise ValueError("dones_out must be a contiguous int32 tensor of num_envs elements on the env's device")
-        if descriptors_out is None and actions_out is None:
+        notify = (self._flag is not None and descriptors_out is None and actions_out is None
+                  and not getattr(self, "_stats_bound", False))
+        if notify:
+            self._flag_seq = seq = (self._flag_seq + 1) & 0x3FFFFFFFFFFFFFFF
+            rc = self._lib.fe_env_step_notify(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
+                                              dones.data_ptr(), self._flag, seq, self._stream())
+        elif descriptors_out is None and actions_out is None:
             rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
                                self._stream())
         else:
@@ -507,7 +550,7 @@ class TimeSeriesEnv:
             info = self.record_evaluation_metrics()
         elif self.redraw == "torch" and self._eval_env >= 0:
             # TSE:504-513: the eval env redraws a day from torch's global generator when it finishes
-            if dones[self._eval_env].item():
+            if self._eval_env_done(seq) if notify else bool(dones[self._eval_env].item()):
                 D = self.price_environments.shape[0]
                 self.env_indices[self._eval_env : self._eval_env + 1] = torch.randint(0, D, (1,), device=self._dev)
         return (obs, rewards, dones, info)

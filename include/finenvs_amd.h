@@ -40,7 +40,7 @@ extern "C" {
 #define FE_OK 0
 #define FE_ERR_ARG -1  /* invalid argument / configuration */
 #define FE_ERR_HIP -2  /* HIP runtime error (no device, launch failure, ...) */
-#define FE_ERR_STATE -3 /* call made before fe_env_bind_state */
+#define FE_ERR_STATE -3 /* call not possible in the env's current state (before fe_env_bind_state; see the entry points) */
 
 /* Constructor arguments of TimeSeriesEnv (TSE:15-29) plus the build's extensions. */
 typedef struct fe_config {
@@ -117,6 +117,24 @@ int fe_env_reset_obs(fe_env *env, void *obs, void *stream);
  */
 int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
                 void *stream);
+
+/*
+ * fe_env_step for the caller that must know on the HOST, every step, whether the evaluation env finished -- the
+ * reference's `if self.dones[-1].item():` (TSE:504-513), which decides whether ONE draw is taken from torch's global
+ * generator before anything else samples from it (redraw_mode 0: exact RNG-stream parity).  Instead of a device-to-host
+ * copy of dones + a stream synchronisation after the whole launch, the kernel accounts the tile that holds the
+ * evaluation env (cfg.eval_env) FIRST and stores (seq << 1) | done into *host_flag -- host memory from
+ * fe_host_flag_create, system scope -- a few microseconds after the launch starts; the host polls the flag until it
+ * carries `seq` (any value that changes per call) and can issue the next launches while this one is still streaming.
+ * Tile order is the only difference to fe_env_step: results are identical.  FE_ERR_ARG if the env has no evaluation env
+ * (evaluate mode, or a shard that does not own it); FE_ERR_STATE while episode statistics are bound (fe_env_bind_stats:
+ * this is the lean kernel -- use fe_env_step and read dones[eval_env] there).
+ */
+int fe_env_step_notify(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                       uint64_t *host_flag, uint64_t seq, void *stream);
+/* A host-resident, device-visible, coherent 8-byte flag for fe_env_step_notify (TSE:510 is the host read it serves); zeroed. */
+int fe_host_flag_create(uint64_t **host_flag);
+int fe_host_flag_destroy(uint64_t *host_flag);
 
 /*
  * Optional, f32 observations only: an f32 copy (D, L, 4*A) of the log-return table, cast by the

@@ -287,3 +287,79 @@ def test_non_f32_actions_are_refused_unless_cast(fe, fo):
     assert_bits(t2n(o), t2n(o32), "obs")
     assert_bits(t2n(r), t2n(r32), "rewards")
     assert_bits(t2n(d), t2n(d32), "dones")
+
+
+@pytest.mark.parametrize("N,A,W,dt", [(1003, 1, 16, torch.float64), (4099, 1, 64, torch.float32), (77, 3, 8, torch.float64)])
+def test_step_notify_equals_step_and_reports_the_eval_env_early(fe, fo, N, A, W, dt):
+    """fe_env_step_notify (the default mode's per-step host read, TSE:510): same results as fe_env_step bit for bit --
+    only the tile order differs --, and the host flag carries (seq << 1) | done of the evaluation env."""
+    import ctypes as C
+
+    from finenvs_amd import _lib
+    from finenvs_amd.data import synthetic
+
+    prices, day_id, _ = synthetic.synthetic_series(8, A, 30, 21, 0.05)
+    mk = lambda: fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", seed=5, obs_dtype=dt)
+    a_env, b_env = mk(), mk()
+    lib = a_env._lib
+    flag = C.c_void_p()
+    _lib.check(lib.fe_host_flag_create(C.byref(flag)))
+    word = C.c_uint64.from_address(flag.value)
+    assert word.value == 0
+    g = torch.Generator(device="cuda").manual_seed(2)
+    obs = torch.empty((N, W, 5 * A), dtype=dt, device="cuda")
+    rew = torch.empty((N,), dtype=torch.float64, device="cuda")
+    done = torch.empty((N,), dtype=torch.int32, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    seen_done = 0
+    for k in range(1, 45):
+        a = (torch.rand((N, A), generator=g, device="cuda") * 2 - 1).float()
+        _lib.check(lib.fe_env_step_notify(a_env._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), flag, 1000 + k, st))
+        o2, r2, d2, _ = b_env.step(a)
+        torch.cuda.synchronize()
+        assert word.value >> 1 == 1000 + k
+        assert (word.value & 1) == int(done[-1]), "the flag's low bit is the evaluation env's done flag"
+        seen_done += word.value & 1
+        assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(done, d2)
+        for x, y in ((a_env.cash, b_env.cash), (a_env.margin, b_env.margin), (a_env._spot0, b_env._spot0), (a_env.env_indices, b_env.env_indices)):
+            assert torch.equal(x, y)
+    assert seen_done >= 1  # 30-bar days: the evaluation env finished at least once (and redrew its day identically)
+    # no evaluation env -> refused; episode statistics bound -> refused (this is the lean kernel)
+    ev = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, evaluate=True, obs_dtype=dt)
+    rc = lib.fe_env_step_notify(ev._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), flag, 1, st)
+    assert rc == _lib.FE_ERR_ARG and b"evaluation env" in lib.fe_last_error()
+    from finenvs_amd.stats import EpisodeStats
+
+    stats = EpisodeStats(a_env)
+    rc = lib.fe_env_step_notify(a_env._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), flag, 2, st)
+    assert rc == _lib.FE_ERR_STATE
+    stats.close()
+    torch.cuda.synchronize()
+    _lib.check(lib.fe_host_flag_destroy(flag))
+
+
+def test_default_mode_polls_the_host_flag_and_keeps_the_reference_rng_stream(fe, fo):
+    """redraw="torch" (the class default): step() decides the evaluation env's redraw from the host flag; the draws it
+    takes from torch's global generator are the ones the plain dones[-1].item() path takes (same seed -> same day
+    sequence, same generator state afterwards), also while episode statistics force the plain path."""
+    from finenvs_amd.data import synthetic
+    from finenvs_amd.stats import EpisodeStats
+
+    prices, day_id, _ = synthetic.synthetic_series(7, 1, 24, 8)
+    runs = []
+    for plain in (False, True):
+        torch.manual_seed(99)
+        env = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=4, num_envs=9)
+        assert env.redraw == "torch" and env._flag is not None
+        stats = EpisodeStats(env) if plain else None  # bound statistics -> step() uses fe_env_step + .item()
+        g = torch.Generator(device="cuda").manual_seed(1)
+        days = []
+        for _ in range(120):
+            env.step((torch.rand((9, 1), generator=g, device="cuda") * 2 - 1).float())
+            days.append(int(env.env_indices[-1]))
+        runs.append((days, torch.rand(3).tolist(), env.cash.clone()))
+        if stats is not None:
+            stats.close()
+    assert runs[0][0] == runs[1][0] and len(set(runs[0][0])) > 1
+    assert runs[0][1] == runs[1][1], "the global generator must be in the same state afterwards"
+    assert torch.equal(runs[0][2], runs[1][2])

@@ -28,8 +28,8 @@ def table():
 
 def test_streaming_kernels_use_no_scratch(table):
     streaming = [r for r in table if re.match(r"fe_(env|render|describe)_kernel", r["name"])]
-    # 5 (dtype x pack width) x 2 (single / multi asset) x (reset + lean step + full step), + render and describe
-    assert len([r for r in streaming if r["name"].startswith("fe_env_kernel")]) == 30
+    # 5 (dtype x pack width) x 2 (single / multi asset) x (reset + three forms of the step), + render and describe
+    assert len([r for r in streaming if r["name"].startswith("fe_env_kernel")]) == 40
     assert len([r for r in streaming if r["name"].startswith("fe_render_kernel")]) == 10
     bad = [(r["name"], r["scratch"], r["vgpr_spill"]) for r in streaming if r["scratch"] != 0 or r["vgpr_spill"] != 0]
     assert not bad, f"scratch / VGPR spills in streaming kernels: {bad}"
@@ -38,10 +38,12 @@ def test_streaming_kernels_use_no_scratch(table):
 def test_step_kernels_keep_their_occupancy(table):
     """The launch geometry (fe_env.hip:configure_launch) assumes these wavefronts per SIMD."""
     want = {
-        "fe_env_kernel<double, 2, true, false, false>": 4,   # single asset, f64: 4 workgroups per CU
-        "fe_env_kernel<float, 4, true, false, false>": 6,    # single asset, f32: 6
-        "fe_env_kernel<double, 2, false, false, false>": 6,  # multi asset
-        "fe_env_kernel<double, 2, true, true, false>": 7,    # reset()
+        "fe_env_kernel<double, 2, true, false, 0>": 4,   # single asset, f64: 4 workgroups per CU (lean form)
+        "fe_env_kernel<double, 2, true, false, 1>": 4,   # ... full form
+        "fe_env_kernel<double, 2, true, false, 2>": 4,   # ... lean + host flag
+        "fe_env_kernel<float, 4, true, false, 0>": 6,    # single asset, f32: 6
+        "fe_env_kernel<double, 2, false, false, 0>": 6,  # multi asset
+        "fe_env_kernel<double, 2, true, true, 0>": 7,    # reset()
     }
     got = {r["name"]: r["occupancy"] for r in table}
     for name, waves in want.items():
@@ -49,11 +51,12 @@ def test_step_kernels_keep_their_occupancy(table):
 
 
 def test_lean_step_kernel_has_fewer_scalar_spills_than_the_full_one(table):
-    """fe_env_kernel<..., FULL = false> exists so that the optional outputs' pointers never become live scalars
+    """fe_env_kernel<..., FORM = 0> exists so that the optional outputs' pointers never become live scalars
     (profiles/r03_microbench/lean_vs_full.txt): 48 SGPR spills in round 2's only form, ~10 in the lean one."""
     got = {r["name"]: r["sgpr_spill"] for r in table}
-    assert got["fe_env_kernel<double, 2, true, false, false>"] <= 16
-    assert got["fe_env_kernel<double, 2, true, false, false>"] < got["fe_env_kernel<double, 2, true, false, true>"]
+    assert got["fe_env_kernel<double, 2, true, false, 0>"] <= 16
+    assert got["fe_env_kernel<double, 2, true, false, 0>"] < got["fe_env_kernel<double, 2, true, false, 1>"]
+    assert got["fe_env_kernel<double, 2, true, false, 2>"] < got["fe_env_kernel<double, 2, true, false, 1>"]
 
 
 def test_committed_table_matches_this_build(table):

@@ -17,7 +17,7 @@ import csv, glob, collections, re
 agg = collections.defaultdict(list)
 for f in glob.glob("$OUT/p*/*/*_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        if re.search(r"fe_env_kernel<[^>]*, (?:true|false), false, (?:true|false)>", r["Kernel_Name"]):  # the step kernel (RESET_ONLY = false)
+        if re.search(r"fe_env_kernel<[^>]*, (?:true|false), false, \d+>", r["Kernel_Name"]):  # the step kernel (RESET_ONLY = false)
             agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in sorted(agg.items()):
     print(f"{k:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
