@@ -52,6 +52,7 @@ CONFIGS = {
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 TRAJ_T = 16             # trajectory slots on one GPU (no exchange)
+AUDITION_EXTRA = 10     # ring audition: candidate buffers beyond the ring's own (config 3: 12 x 20 GB fit; config 5: 1; config 4: none)
 TRAJ_BUDGET = 48e9      # bytes of trajectory chunks + gathered copies a rank may hold (N > 1)
 # the reference's own PyTorch-CPU path, measured in the build container
 REFERENCE_CPU_QUOTED = {"value": 40497, "unit": "env-steps/s", "cores": 8,
@@ -234,7 +235,7 @@ def pmc_child(args):
     prices, day_id, _ = make_series(A)
     obs_bytes = N * W * 5 * A * (4 if args.obs_f32 else 8)
     env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw=args.redraw, seed=1234,
-                                    obs_buffers=2 if 2 * obs_bytes < 200e9 else 1, obs_audition=0 if args.no_audition else 5,
+                                    obs_buffers=2 if 2 * obs_bytes < 200e9 else 1, obs_audition=0 if args.no_audition else AUDITION_EXTRA,
                                     obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
     g = torch.Generator(device="cuda:0").manual_seed(7)
     actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
@@ -279,7 +280,7 @@ class Dist:
             if self.backend == "nccl" and os.environ.get("FE_BENCH_RCCL_DEBUG", "1") != "0":
                 self.rccl_log = f"/tmp/fe_bench_rccl_{os.getpid()}.log"
                 os.environ["NCCL_DEBUG"] = "INFO"
-                os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING,ENV,COLL"
+                os.environ["NCCL_DEBUG_SUBSYS"] = "INIT,GRAPH,TUNING,ENV"  # (not COLL: no per-call logging inside timed regions)
                 os.environ["NCCL_DEBUG_FILE"] = self.rccl_log
             if self.backend == "nccl":
                 dist.init_process_group("nccl", device_id=torch.device(self.dev), **kw)
@@ -321,7 +322,6 @@ class Dist:
                 "topology": pick(r"Pattern \d|coll channels|P2P Chunksize|intraNodeP2pSupport|nNodes|XGMI|=== System", 10),
                 "transport": pick(r" via |Connected all", 6),
                 "rings": pick(r"NCCL INFO Ring 0*0 :", 2),
-                "all_gather_calls": len([1 for ln in lines if "NCCL INFO AllGather:" in ln]),
                 "env": pick(r"NCCL_[A-Z_]+ set|RCCL_[A-Z_]+ set", 8)}
 
     def barrier(self):
@@ -413,7 +413,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         g = torch.Generator(device=dev).manual_seed(7 + rank)
         actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
         # The ring as the allocator handed it out is timed FIRST (`as_allocated`); then ring mode's placement audition (a
-        # product feature of the ring) tries up to 5 more candidate buffers and keeps the fastest
+        # product feature of the ring) tries up to AUDITION_EXTRA more candidate buffers (as far as free memory allows) and keeps the fastest
         # (none fit at config 4) -- the headline runs on the auditioned ring, the as-allocated figure is reported beside it.
         as_allocated = None
         if not args.no_audition:
@@ -421,7 +421,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             k_aa = min(max(steps, 20), 400)
             kernel_interval_ms(env, actions, k_aa, runs=1)  # discarded: clocks, tables and state warm before anything is compared
             as_allocated = {"kernel_ms": kernel_interval_ms(env, actions, k_aa, runs=3)}
-            env.audition_ring(5)
+            env.audition_ring(AUDITION_EXTRA)
         # Compact trajectory fields live in a device buffer; the step kernel writes rewards, dones and its copy of the
         # actions straight into slot t (fe_env_step_traj), so storing a step costs no extra launch.  (Round 2 found the
         # earlier scheme -- actions pre-stored in the slots -- to read 256 KB of COLD memory per step once a chunk is longer
