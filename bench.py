@@ -605,8 +605,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
 
 
 REDRAW_CONTRACT = ("eval_redraw='device' (the headline): the evaluation env's day redraws come from a Philox4x32-10 counter "
-                   "inside the step kernel -- THIS BUILD's contract (finenvs_amd/rng.py, pinned against the oracle's restatement of "
-                   "the same generator, not against the reference), no host synchronisation.  eval_redraw='torch' (the class "
+                   "inside the step kernel -- THIS BUILD's contract (finenvs_amd/rng.py; the generator is pinned to Random123's published "
+                   "known-answer vectors and to the oracle's restatement, the day SEQUENCE has no counterpart in the reference), no host synchronisation.  eval_redraw='torch' (the class "
                    "default, timed as `reference_semantics`): the reference's own stream -- one torch.randint on the global "
                    "generator per finished evaluation episode, decided by a per-step host read of dones[-1] (TSE:504-513); the "
                    "reference-generated golden fixtures pin this mode.")

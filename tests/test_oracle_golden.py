@@ -223,24 +223,40 @@ def test_oracle_openmp_threads_do_not_change_results():
 
 
 def test_philox_known_answer():
-    # Random123 known-answer vector for philox4x32-10: counter = key = 0 -> 0x6627e8d5
-    lib = fo.lib()
+    """The device redraw generator is Philox4x32-10 (Salmon et al., SC'11).  Pinned to the PUBLISHED known-answer
+    vectors of Random123's kat_vectors file through a generic four-word implementation, to which the three
+    restatements in this repo -- the oracle's C (fo_philox_u32), the host mirror (finenvs_amd/rng.py) and, through
+    the oracle-vs-HIP rollouts, the kernel's (fe_device_common.h:philox_u32) -- are then tied: they are that function
+    with counter words (ctr_lo, ctr_hi, 0x46454e56, 0) and key (seed_lo, seed_hi), first output word."""
     import ctypes as C
 
-    # our counter layout puts a domain tag in word 2, so check the raw rounds through a
-    # second, independent pure-Python Philox instead
-    def philox(seed, ctr):
-        c = [ctr & 0xFFFFFFFF, ctr >> 32, 0x46454E56, 0]
-        k = [seed & 0xFFFFFFFF, seed >> 32]
-        for _ in range(10):
-            p0 = 0xD2511F53 * c[0]
-            p1 = 0xCD9E8D57 * c[2]
-            c = [(p1 >> 32) ^ c[1] ^ k[0], p1 & 0xFFFFFFFF, (p0 >> 32) ^ c[3] ^ k[1], p0 & 0xFFFFFFFF]
-            k = [(k[0] + 0x9E3779B9) & 0xFFFFFFFF, (k[1] + 0xBB67AE85) & 0xFFFFFFFF]
-        return c[0]
+    from finenvs_amd.rng import philox_u32, redraw_day
 
-    for seed, ctr in [(0, 0), (1, 0), (0x123456789ABCDEF, 7), (42, 2**33 + 5)]:
-        assert lib.fo_philox_u32(C.c_uint64(seed), C.c_uint64(ctr)) == philox(seed, ctr)
+    M0, M1, W0, W1, MASK = 0xD2511F53, 0xCD9E8D57, 0x9E3779B9, 0xBB67AE85, 0xFFFFFFFF
+
+    def philox4x32_10(c, k):
+        c, k = list(c), list(k)
+        for _ in range(10):
+            p0, p1 = M0 * c[0], M1 * c[2]
+            c = [((p1 >> 32) ^ c[1] ^ k[0]) & MASK, p1 & MASK, ((p0 >> 32) ^ c[3] ^ k[1]) & MASK, p0 & MASK]
+            k = [(k[0] + W0) & MASK, (k[1] + W1) & MASK]
+        return c
+
+    # Random123 kat_vectors: "philox4x32 10 <ctr x4> <key x2> <expected x4>"
+    kat = [
+        ([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+        ([MASK] * 4, [MASK] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+        ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0], [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1]),
+    ]
+    for ctr, key, want in kat:
+        assert philox4x32_10(ctr, key) == want
+    lib = fo.lib()
+    for seed, ctr in [(0, 0), (1, 0), (0x123456789ABCDEF, 7), (42, 2**33 + 5), (2**64 - 1, 2**64 - 1)]:
+        want = philox4x32_10([ctr & MASK, ctr >> 32, 0x46454E56, 0], [seed & MASK, seed >> 32])[0]
+        assert lib.fo_philox_u32(C.c_uint64(seed), C.c_uint64(ctr)) == want
+        assert philox_u32(seed, ctr) == want
+    for i in range(50):
+        assert lib.fo_redraw_day(C.c_uint64(9), C.c_uint64(i), C.c_int64(64)) == redraw_day(9, i, 64)
     days = [lib.fo_redraw_day(C.c_uint64(9), C.c_uint64(i), C.c_int64(64)) for i in range(2000)]
     assert min(days) == 0 and max(days) == 63
 
