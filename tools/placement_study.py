@@ -4,6 +4,9 @@
     python tools/placement_study.py separate     # 10 separate torch allocations (what the ring audition sees)
     python tools/placement_study.py slab         # ONE 200 GB allocation carved into 10 windows at 20 GB steps
     python tools/placement_study.py offsets      # one 60 GB allocation, the same 20 GB window shifted by 0 .. 1 GiB
+    python tools/placement_study.py contig | hipmalloc   # raw HIP allocations, physically contiguous / plain
+    python tools/placement_study.py scan         # sixteenths of a contiguous and of two torch buffers
+    python tools/placement_study.py sequence     # 13 x 20 GB in a row, twice; then behind 160 / 80 GB of ballast
 
 Run each also under PYTORCH_HIP_ALLOC_CONF=expandable_segments:True (torch then maps fixed-size physical granules).
 """
@@ -79,6 +82,35 @@ elif mode == "scan":
         parts = [time_into(base + k * (n // 16) * 8) for k in range(16)]
         print(f"{label:11s} whole buffer {full:8.1f} us ({n * 8 / full / 1e6:5.2f} TB/s); sixteenths (TB/s): "
               + " ".join(f"{(n // 16) * 8 / t / 1e6:5.2f}" for t in parts), flush=True)
+    sys.exit(0)
+elif mode == "sequence":
+    # is a buffer's speed a function of WHEN (= where) it was allocated?  13 x 20 GB in a row, twice; then 160 GB of
+    # ballast first and six buffers behind it
+    import ctypes as C
+
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMalloc.argtypes = [C.POINTER(C.c_void_p), C.c_size_t]
+    hip.hipFree.argtypes = [C.c_void_p]
+
+    def alloc(nbytes):
+        p = C.c_void_p()
+        rc = hip.hipMalloc(C.byref(p), nbytes)
+        return p.value if rc == 0 else None
+
+    for label, ballast, count in (("A: 13 in a row", 0, 13), ("B: again", 0, 13), ("C: 160 GB ballast first", 160e9, 6), ("D: 80 GB ballast first", 80e9, 9)):
+        bal = alloc(int(ballast)) if ballast else None
+        ptrs = []
+        for i in range(count):
+            p = alloc(n * 8)
+            if p is None:
+                break
+            ptrs.append(p)
+        speeds = [n * 8 / time_into(p) / 1e6 for p in ptrs]
+        print(f"{label:26s}: " + " ".join(f"{x:5.2f}" for x in speeds) + "  TB/s", flush=True)
+        for p in ptrs:
+            hip.hipFree(p)
+        if bal:
+            hip.hipFree(bal)
     sys.exit(0)
 elif mode in ("contig", "hipmalloc", "uncached"):
     # raw HIP allocations: physically contiguous (hipDeviceMallocContiguous) / plain hipMalloc / uncached, outside torch's allocator
