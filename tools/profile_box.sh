@@ -4,7 +4,7 @@
 set -o pipefail
 CFG=${1:-2}; STEPS=${2:-200}; TAG=${3:-r02}; F32=${4:-}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-EXTRA="--no-cpu --no-extra --no-pmc --repeats 2"
+EXTRA="--no-cpu --no-extra --no-pmc --no-audition --repeats 2"  # as-allocated ring: every launch of the run writes the same buffers
 SUF=""
 if [ "$F32" = "f32" ]; then EXTRA="$EXTRA --obs-f32"; SUF="_f32"; fi
 OUT=$ROOT/gpurun_out/prof_${TAG}_c${CFG}${SUF}

@@ -60,7 +60,7 @@ avg = float(step["AverageNs"])
 key = f"{tag}_c{cfg}" + ("_f32" if bench["dtype"] == "f32" else "")
 with open(os.path.join(dst, f"{key}_summary.md"), "w") as f:
     f.write(f"# {tag} config {cfg}: {bench['config']['workload']} ({bench['dtype']} observations)\n\n")
-    f.write(f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config {cfg} --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu --no-extra{' --obs-f32' if bench['dtype'] == 'f32' else ''}` (+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)\n\n")
+    f.write(f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config {cfg} --steps {bench['steps']} --warmup {bench['warmup']} --no-cpu --no-extra --no-audition{' --obs-f32' if bench['dtype'] == 'f32' else ''}` (+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes)\n\n")
     f.write(f"* step kernel `{short(step['Name'])}`: {step['Calls']} calls, avg {avg/1e3:.2f} us, min {float(step['MinNs'])/1e3:.2f} us, max {float(step['MaxNs'])/1e3:.2f} us ({step['Percentage']} % of GPU time)\n")
     f.write(f"* bench.py under the profiler: {bench['value']:.4g} env-steps/s, {bench['ms_per_step']*1e3:.2f} us/step wall (median of {bench['repeats']['single_gpu']['blocks']} blocks), HIP-event average launch interval {r['kernel_ms']*1e3:.2f} us (kernel + launch boundary, tight C-ABI loop)\n")
     f.write(f"* HBM bytes that must move per launch (observation write + state + outputs): {Bh} B x {N} envs = {Bh*N/1e6:.1f} MB -> {Bh*N/avg:.0f} GB/s at the rocprof average = **{Bh*N/avg/8000*100:.1f} % of 8 TB/s** (this is bench.py's `roofline.achieved` / `frac`)\n")
