@@ -604,6 +604,57 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     return res
 
 
+def two_stream_leg(args, steps: int):
+    """The headline workload as TWO contiguous shards (rank 0 / 1 of 2: the same envs, the evaluation env in the second)
+    stepped on two HIP streams.  Envs are independent, so a rollout loop that evaluates its policy per shard (a
+    double-buffered sampler, examples/double_buffered_rollout.py) lets one shard's start-up chain and launch boundary
+    overlap the other shard's store stream across steps.  Launches go through the C ABI (pre-generated actions, as in the
+    headline's kernel-interval loop).  Never part of `value`."""
+    import finenvs_amd
+
+    name, N, A, W = CONFIGS[2]
+    prices, day_id, _ = make_series(A)
+    dev = "cuda:0"
+    parts, streams = [], [torch.cuda.Stream(), torch.cuda.Stream()]
+    for r in range(2):
+        env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, rank=r, world_size=2,
+                                        redraw="device", seed=1234, obs_buffers=2)
+        n = env.num_envs
+        g = torch.Generator(device=dev).manual_seed(7 + r)
+        acts = [(torch.rand((n, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
+        env.reset()
+        parts.append((env, acts, torch.empty((n,), dtype=torch.float64, device=dev), torch.empty((n,), dtype=torch.int32, device=dev)))
+    k2 = min(max(steps, 20), 400)
+    times = []
+    for rep in range(4):
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for s_ in streams:
+            s_.wait_event(e0)
+        for k in range(k2):
+            for (env, acts, rew, done), s_ in zip(parts, streams):
+                rc = env._step_fn(env._handle_v, acts[k % 8].data_ptr(), env._obs_ring[k % 2].data_ptr(), rew.data_ptr(), done.data_ptr(),
+                                  s_.cuda_stream)
+        for s_ in streams:
+            torch.cuda.current_stream().wait_stream(s_)
+        e1.record()
+        torch.cuda.synchronize()
+        from finenvs_amd import _lib as _fl
+
+        _fl.check(rc)
+        if rep:
+            times.append(e0.elapsed_time(e1) / k2)
+    ms = statistics.median(times)
+    Bh = hbm_bytes(W, A, 8)
+    del parts
+    torch.cuda.empty_cache()
+    return {"workload": name, "what": "two contiguous shards (rank 0 / 1 of 2) of the same 65 536 envs on two HIP streams, C-ABI launches, "
+                                      "HIP events around the whole loop", "envs": N, "ms_per_step_all_envs": ms,
+            "value": N / ms * 1e3, "unit": "env-steps/s", "achieved_GBps": Bh * N / (ms * 1e-3) / 1e9,
+            "frac_of_8TBps": Bh * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches_per_run": 2 * k2}
+
+
 REDRAW_CONTRACT = ("eval_redraw='device' (the headline): the evaluation env's day redraws come from a Philox4x32-10 counter "
                    "inside the step kernel -- THIS BUILD's contract (finenvs_amd/rng.py; the generator is pinned to Random123's published "
                    "known-answer vectors and to the oracle's restatement, the day SEQUENCE has no counterpart in the reference), no host synchronisation.  eval_redraw='torch' (the class "
@@ -767,13 +818,17 @@ def main():
                 extras.append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
                 break
 
-    fused = refsem = None
+    fused = refsem = two_streams = None
     if not D.multi and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
         fused = fused_rollout_legs(args)
         try:
             refsem = reference_semantics_leg(args, args.steps)
         except Exception as exc:  # noqa: BLE001
             refsem = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            two_streams = two_stream_leg(args, args.steps)
+        except Exception as exc:  # noqa: BLE001
+            two_streams = {"error": f"{type(exc).__name__}: {exc}"}
 
     if D.rank == 0:
         out = {
@@ -805,6 +860,7 @@ def main():
             "extra_configs": [{k: v for k, v in e.items() if k != "cpu_baseline"} for e in extras],
             "fused_rollouts": fused,
             "reference_semantics": refsem,
+            "two_streams": two_streams,
         }
     else:
         out = None
