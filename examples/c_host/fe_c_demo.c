@@ -7,7 +7,11 @@
  *
  *   gcc -O2 examples/c_host/fe_c_demo.c -I include -I /opt/rocm/include -L finenvs_amd/csrc -lfinenvs_amd \
  *       -L /opt/rocm/lib -lamdhip64 -Wl,-rpath,$PWD/finenvs_amd/csrc -Wl,-rpath,/opt/rocm/lib -lm \
- *       -o /tmp/fe_c_demo && /tmp/fe_c_demo 4096 16 200
+ *       -o /tmp/fe_c_demo && /tmp/fe_c_demo 4096 16 200 [notify]
+ *
+ * With a fourth argument "notify" the steps go through fe_env_step_notify: the host learns whether the evaluation env
+ * finished (the reference's per-step `if self.dones[-1].item():`, TSE:510) by polling a coherent host word that the kernel
+ * writes a few microseconds into the launch, instead of copying dones back; every printed number must be the same.
  */
 #define __HIP_PLATFORM_AMD__ 1
 #include <hip/hip_runtime_api.h>
@@ -25,6 +29,7 @@ int main(int argc, char **argv) {
     const int64_t N = argc > 1 ? atoll(argv[1]) : 4096;
     const int32_t W = argc > 2 ? atoi(argv[2]) : 16;
     const int steps = argc > 3 ? atoi(argv[3]) : 200;
+    const int notify = argc > 4 && argv[4][0] == 'n';
     const int32_t A = 1;
     const int64_t days = 6, bars = 50, T = days * bars;
     if (fe_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
@@ -103,15 +108,27 @@ int main(int argc, char **argv) {
     double *h_rew = (double *)malloc(sizeof(double) * N);
     int32_t *h_done = (int32_t *)malloc(sizeof(int32_t) * N);
     double rew_sum = 0.0;
-    long long dones = 0;
+    long long dones = 0, eval_dones_flag = 0, eval_dones = 0;
+    uint64_t *flag = NULL;
+    if (notify) FECK(fe_host_flag_create(&flag));
     for (int s = 0; s < steps; ++s) {
         for (int64_t n = 0; n < N; ++n) h_act[n] = (float)sin(0.013 * (double)(n + 1) * (double)(s + 1));
         HIPCK(hipMemcpy(d_act, h_act, sizeof(float) * N, hipMemcpyHostToDevice));
-        FECK(fe_env_step(env, d_act, d_obs, d_rew, d_done, NULL));
+        if (notify) {
+            const uint64_t seq = (uint64_t)s + 1;
+            FECK(fe_env_step_notify(env, d_act, d_obs, d_rew, d_done, flag, seq, NULL));
+            uint64_t v;
+            while (((v = *(volatile uint64_t *)flag) >> 1) != seq) { /* the launch is still running; only the flag is awaited */ }
+            eval_dones_flag += (long long)(v & 1);
+        } else {
+            FECK(fe_env_step(env, d_act, d_obs, d_rew, d_done, NULL));
+        }
         HIPCK(hipMemcpy(h_rew, d_rew, sizeof(double) * N, hipMemcpyDeviceToHost));
         HIPCK(hipMemcpy(h_done, d_done, sizeof(int32_t) * N, hipMemcpyDeviceToHost));
         for (int64_t n = 0; n < N; ++n) { rew_sum += h_rew[n]; dones += h_done[n]; }
+        eval_dones += h_done[N - 1];
     }
+    if (notify && eval_dones_flag != eval_dones) { fprintf(stderr, "host flag saw %lld evaluation-env dones, dones[N-1] %lld\n", eval_dones_flag, eval_dones); return 4; }
     HIPCK(hipMemcpy(h_cash, d_cash, sizeof(float) * N, hipMemcpyDeviceToHost));
     double cash_sum = 0.0;
     for (int64_t n = 0; n < N; ++n) cash_sum += (double)h_cash[n];
@@ -123,7 +140,8 @@ int main(int argc, char **argv) {
     FECK(fe_env_launch_info(env, &grid, &block, &tile, &lds));
     printf("abi=%d N=%lld W=%d D=%lld L=%lld steps=%d grid=%d tile=%d\n", fe_version(), (long long)N, W, (long long)D,
            (long long)L, steps, grid, tile);
-    printf("reward_sum=%.17g dones=%lld cash_sum=%.17g last_obs_sum=%.17g\n", rew_sum, dones, cash_sum, obs_sum);
+    printf("reward_sum=%.17g dones=%lld cash_sum=%.17g last_obs_sum=%.17g eval_dones=%lld\n", rew_sum, dones, cash_sum, obs_sum, eval_dones);
+    if (flag) FECK(fe_host_flag_destroy(flag));
     FECK(fe_env_destroy(env));
     return 0;
 }
