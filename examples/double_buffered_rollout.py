@@ -4,12 +4,11 @@ contiguous shards of the same env batch, each on its own HIP stream.
 
 Envs are independent and the reference's actor acts per env, so `policy(states)` can be evaluated per shard:
 
-    shards  = [TimeSeriesEnv(..., num_envs=N, rank=i, world_size=2, redraw="device", obs_buffers=2) for i in (0, 1)]
-    rolls   = [GraphedRollout(env, policy, K) for env in shards]       # K x (policy -> env.step) captured per shard
+    roll = DoubleBufferedRollout(lambda rank, world: TimeSeriesEnv(..., num_envs=N, rank=rank, world_size=world,
+                                                                   redraw="device", obs_buffers=2), policy, K)
     for _ in range(replays):
-        for roll, stream in zip(rolls, streams):
-            with torch.cuda.stream(stream):
-                roll.run()
+        roll.run()                          # K x (policy -> env.step) per shard, one hipGraph and one HIP stream each
+    obs_per_shard = roll.join()             # the shards drift apart between joins: that IS the overlap
 
 The two shards together ARE the unsharded env (same env numbering, same day per env, the evaluation env is the last env of
 the second shard; tests/test_sharded_env_gpu.py; this script checks the account state bit for bit), but the GPU now always
@@ -18,7 +17,7 @@ has one shard streaming its observations while the other shard's launch boundary
 the trick needs a GPU-bound loop: issued eagerly from Python, two shards are twice the host work and the host is the
 bottleneck.  Measured at 65 536 envs x W64: pre-generated actions 29.5 -> 26.3 us per step of all envs (C-ABI launches,
 tools/two_stream_bench.py; `two_streams` in bench.py's line: 2.4 G env-steps/s, 0.80 of 8 TB/s); with this script's small
-torch policy in the graphs 65.6 -> 58.4 us (1.12 x).
+torch policy in the graphs 65 -> 57 us (1.15 x).
 
     python examples/double_buffered_rollout.py [--envs 65536] [--window 64] [--replays 50] [--k 8] [--hidden 32]
 """
@@ -33,7 +32,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from finenvs_amd import TimeSeriesEnv  # noqa: E402
 from finenvs_amd.data import synthetic  # noqa: E402
-from finenvs_amd.rollout import GraphedRollout  # noqa: E402
+from finenvs_amd.rollout import DoubleBufferedRollout, GraphedRollout  # noqa: E402
 
 
 class TinyPolicy(torch.nn.Module):
@@ -48,14 +47,13 @@ class TinyPolicy(torch.nn.Module):
         return self.net(states[:, -1, :].float())
 
 
-def rollout(rolls, streams, replays):
-    """`replays` replays of every shard's K-step hipGraph (policy -> env.step, K times), shard i on streams[i]."""
+def timed(roll, replays):
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(replays):
-        for roll, s in zip(rolls, streams):
-            with torch.cuda.stream(s):
-                roll.run()
+        roll.run()
+    if hasattr(roll, "join"):
+        roll.join()
     torch.cuda.synchronize()
     return time.perf_counter() - t0
 
@@ -78,18 +76,16 @@ def main():
     # is out of the way and what is compared is GPU time
     one = TimeSeriesEnv(**kw)
     roll1 = GraphedRollout(one, act, args.k)
-    rollout([roll1], [torch.cuda.current_stream()], 5)
-    dt1 = rollout([roll1], [torch.cuda.current_stream()], args.replays)
+    timed(roll1, 5)
+    dt1 = timed(roll1, args.replays)
     cash1 = one.cash.clone()
     del roll1, one
     torch.cuda.empty_cache()
 
-    shards = [TimeSeriesEnv(rank=r, world_size=2, **kw) for r in range(2)]
-    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
-    rolls = [GraphedRollout(e, act, args.k) for e in shards]
-    rollout(rolls, streams, 5)
-    dt2 = rollout(rolls, streams, args.replays)
-    cash2 = torch.cat([e.cash for e in shards])
+    roll2 = DoubleBufferedRollout(lambda rank, world: TimeSeriesEnv(rank=rank, world_size=world, **kw), act, args.k, shards=2)
+    timed(roll2, 5)
+    dt2 = timed(roll2, args.replays)
+    cash2 = torch.cat([e.cash for e in roll2.envs])
 
     n = args.envs * args.k * args.replays
     per1, per2 = dt1 / (args.k * args.replays) * 1e6, dt2 / (args.k * args.replays) * 1e6

@@ -110,6 +110,101 @@ class GraphedRollout:
         raise RuntimeError("episodes did not all terminate within max_steps")
 
 
+class DoubleBufferedRollout:
+    """The env batch as ``shards`` contiguous shards (``rank = i, world_size = shards`` on ONE device: the very same envs,
+    env n -> day n mod D, the evaluation env in the last shard), one ``GraphedRollout`` per shard, each replayed on its
+    own HIP stream.  Envs are independent, so when the policy acts per env (the reference's actors do) the shards need
+    not wait for each other: while one shard's launch boundary, first-tile chain and policy run, the other shard's
+    observation stream keeps HBM busy -- the ~4 us per step that a single 30 us launch cannot hide (DESIGN.md section
+    5: 29.5 -> 26.3 us per step of all 65 536 envs; two shards is the sweet spot, four gain nothing).
+
+    ``make_env(rank, world_size)`` must return a ``TimeSeriesEnv`` built with exactly those ``rank`` / ``world_size``
+    (and ``redraw="device"``, ``obs_buffers >= 1``: what ``GraphedRollout`` needs).  ``policy(obs, k)`` is called with
+    ONE shard's observation.  ``rewards`` / ``dones`` are per-shard lists of the K per-step tensors of the last replay
+    (``joined_rewards()`` / ``joined_dones()``: (K, N) in global env order).
+
+    Stream semantics: the shards run on their own streams and must be allowed to DRIFT APART -- if they are brought
+    together after every replay they start every replay in lock-step, both in their start-up at the same time, and
+    the overlap is gone (measured: 0.99 x instead of 1.12 x).  So ``run()`` only forks from the caller's stream the
+    first time (and after a ``join()``); it does not make the caller's stream wait.  Call ``join()`` before consuming
+    ``obs`` / ``rewards`` / ``dones`` / env state on the current stream, typically once per chunk of replays."""
+
+    def __init__(self, make_env: Callable[[int, int], object], policy: Callable[[torch.Tensor, int], torch.Tensor],
+                 num_steps: int, shards: int = 2, stagger: bool = True):
+        if shards < 1:
+            raise ValueError("shards must be >= 1")
+        self.envs = [make_env(r, shards) for r in range(shards)]
+        for r, env in enumerate(self.envs):
+            if env.rank != r or env.world_size != shards:
+                raise ValueError("make_env(rank, world_size) must pass both on to TimeSeriesEnv")
+            if env._dev != self.envs[0]._dev:
+                raise ValueError("all shards live on one device (for several GPUs use one process per GPU)")
+        self._dev = self.envs[0]._dev
+        self.streams = [torch.cuda.Stream(device=self._dev) for _ in self.envs]
+        self.rolls = [GraphedRollout(env, policy, num_steps) for env in self.envs]
+        self.K = int(num_steps)
+        self.num_envs = sum(env.num_envs for env in self.envs)
+        self._forked = False
+        # Stagger: shard i starts i / shards of a step late, so that the shards run in anti-phase from the first replay
+        # on (two equal graphs started together would march in lock-step, both in their start-up at the same time).
+        # One shard's step time is measured here (outputs unaffected: the replays below are ordinary rollout steps).
+        self._stagger_cycles = 0
+        if stagger and shards > 1:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            probe = GraphedRollout(make_env(0, shards), policy, num_steps)  # a throw-away twin of shard 0
+            probe.run()
+            e0.record()
+            probe.run()
+            e1.record()
+            e1.synchronize()
+            step_ms = e0.elapsed_time(e1) / self.K
+            # torch.cuda._sleep counts device clock ticks of unknown rate: calibrate it with events
+            torch.cuda._sleep(1_000_000)
+            e0.record()
+            torch.cuda._sleep(4_000_000)
+            e1.record()
+            e1.synchronize()
+            ticks_per_ms = 4_000_000 / max(e0.elapsed_time(e1), 1e-3)
+            self._stagger_cycles = int(step_ms / shards * ticks_per_ms)
+            del probe
+
+    def run(self) -> None:
+        """One replay (K steps) of every shard, asynchronously on the shards' streams."""
+        if not self._forked:  # whatever the caller queued so far (e.g. new policy weights) comes first
+            cur = torch.cuda.current_stream(self._dev)
+            for i, s in enumerate(self.streams):
+                s.wait_stream(cur)
+                if i and self._stagger_cycles:
+                    with torch.cuda.stream(s):
+                        torch.cuda._sleep(i * self._stagger_cycles)
+            self._forked = True
+        for roll, s in zip(self.rolls, self.streams):
+            with torch.cuda.stream(s):
+                roll.run()
+
+    def join(self) -> List[torch.Tensor]:
+        """Make the current stream wait for all shards; returns the shards' newest observations."""
+        cur = torch.cuda.current_stream(self._dev)
+        for s in self.streams:
+            cur.wait_stream(s)
+        self._forked = False
+        return [roll.obs for roll in self.rolls]
+
+    @property
+    def rewards(self) -> List[List[torch.Tensor]]:
+        return [roll.rewards for roll in self.rolls]
+
+    @property
+    def dones(self) -> List[List[torch.Tensor]]:
+        return [roll.dones for roll in self.rolls]
+
+    def joined_rewards(self) -> torch.Tensor:
+        return torch.cat([torch.stack(r) for r in self.rewards], dim=1)
+
+    def joined_dones(self) -> torch.Tensor:
+        return torch.cat([torch.stack(d) for d in self.dones], dim=1)
+
+
 class _FusedEvaluation:
     """Shared by the fused rollouts (each has ``env``, ``obs_src (N,)``, ``obs_pos (N, A)`` and ``run``): descriptor
     upkeep, observation on demand, and the reference's evaluation loop on the device."""

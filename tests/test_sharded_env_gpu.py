@@ -92,3 +92,40 @@ def test_two_sharded_ranks_equal_one_unsharded_env():
         lo, hi = finenvs_amd.shard_range(N_TOTAL, rank, world)
         assert np.array_equal(idx, env.env_indices.cpu().numpy()[lo:hi])  # incl. the eval env's redrawn day
         assert np.array_equal(acts[rank][3][: hi - lo], _actions(3)[lo:hi].numpy())
+
+
+def test_double_buffered_rollout_equals_the_unsharded_graphed_rollout():
+    """DoubleBufferedRollout: two shards, two hipGraphs, two streams -- bit for bit what ONE GraphedRollout over the
+    unsharded env gives (per-env policy), over several replays that cross day ends, including the evaluation env's
+    device redraws (it lives in the second shard)."""
+    import finenvs_amd as fe
+    from finenvs_amd.data import synthetic
+    from finenvs_amd.rollout import DoubleBufferedRollout, GraphedRollout
+
+    prices, day_id, _ = synthetic.synthetic_series(6, 1, 24, 5, 0.05)
+    N, W, K = 1001, 8, 6
+    kw = dict(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", seed=11, obs_buffers=2)
+    w = torch.linspace(-3.0, 3.0, 5, dtype=torch.float64, device="cuda")
+
+    def policy(obs, k):  # per env, deterministic: a function of the env's own last row only
+        return torch.tanh((obs[:, -1, :] * w).sum(dim=1, keepdim=True) * (k + 1)).float()
+
+    whole = fe.TimeSeriesEnv(**kw)
+    ref = GraphedRollout(whole, policy, K)
+    dbl = DoubleBufferedRollout(lambda r, ws: fe.TimeSeriesEnv(rank=r, world_size=ws, **kw), policy, K, shards=2)
+    assert dbl.num_envs == N and [e.num_envs for e in dbl.envs] == [501, 500]
+    redraws = 0
+    for rep in range(12):
+        o_ref = ref.run()
+        dbl.run()
+        o_dbl = dbl.join()
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat(o_dbl), o_ref), f"replay {rep}: observations"
+        assert torch.equal(dbl.joined_rewards(), torch.stack(ref.rewards)), f"replay {rep}: rewards"
+        assert torch.equal(dbl.joined_dones(), torch.stack(ref.dones)), f"replay {rep}: dones"
+        assert torch.equal(torch.cat([e.cash for e in dbl.envs]), whole.cash)
+        assert torch.equal(torch.cat([e.env_indices for e in dbl.envs]), whole.env_indices)
+        redraws += int(torch.stack(ref.dones)[:, -1].sum())
+    assert redraws >= 2  # the evaluation env finished (and redrew its day identically) more than once
+    with pytest.raises(ValueError):
+        DoubleBufferedRollout(lambda r, ws: fe.TimeSeriesEnv(**kw), policy, K)  # make_env ignored rank / world_size
