@@ -363,3 +363,47 @@ def test_default_mode_polls_the_host_flag_and_keeps_the_reference_rng_stream(fe,
     assert runs[0][0] == runs[1][0] and len(set(runs[0][0])) > 1
     assert runs[0][1] == runs[1][1], "the global generator must be in the same state afterwards"
     assert torch.equal(runs[0][2], runs[1][2])
+
+
+def test_env_objects_can_be_driven_from_different_host_threads(fe, fo):
+    """one env object is driven from one host thread at a time, but the C ABI is re-entrant ACROSS
+    env objects (per-call parameter block, thread-local error text, a mutex around the launch-preparation cache).  Four
+    threads, each with its own env, stream and fused MLP rollout (which goes through that cache), stepping
+    concurrently: every thread gets what it gets alone."""
+    import threading
+
+    from finenvs_amd.data import synthetic
+    from finenvs_amd.rollout import FusedMLPRollout
+
+    prices, day_id, _ = synthetic.synthetic_series(6, 1, 40, 3)
+    g = torch.Generator().manual_seed(0)
+    W1, b1, W2 = torch.randn((40, 32), generator=g) * 0.5, torch.randn(32, generator=g) * 0.1, torch.randn(32, generator=g) * 0.3
+
+    def work(seed, out, use_stream):
+        env = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=8, num_envs=700 + seed, redraw="device", seed=seed)
+        ga = torch.Generator(device="cuda").manual_seed(seed)
+        s = torch.cuda.Stream() if use_stream else torch.cuda.current_stream()
+        with torch.cuda.stream(s):
+            tot = torch.zeros((), dtype=torch.float64, device="cuda")
+            for _ in range(150):
+                a = (torch.rand((env.num_envs, 1), generator=ga, device="cuda") * 2 - 1).float()
+                _, r, _, _ = env.step(a)
+                tot += r.sum()
+            roll = FusedMLPRollout(env, W1, b1, W2, 0.0, activation="relu")
+            _, r2, _ = roll.run(20, record_actions=False)
+            tot += r2.sum()
+            s.synchronize()
+        out[seed] = (float(tot), env.cash.clone())
+
+    alone, together = {}, {}
+    for seed in range(4):
+        work(seed, alone, False)
+    threads = [threading.Thread(target=work, args=(seed, together, True)) for seed in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join(120)
+        assert not t.is_alive()
+    for seed in range(4):
+        assert together[seed][0] == alone[seed][0], seed
+        assert torch.equal(together[seed][1], alone[seed][1]), seed
