@@ -149,7 +149,7 @@ class DoubleBufferedRollout:
         # on (two equal graphs started together would march in lock-step, both in their start-up at the same time).
         # One shard's step time is measured here (outputs unaffected: the replays below are ordinary rollout steps).
         self._stagger_cycles = 0
-        if stagger and shards > 1:
+        if stagger and shards > 1 and hasattr(torch.cuda, "_sleep"):  # (a private torch helper: without it, no stagger)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             probe = GraphedRollout(make_env(0, shards), policy, num_steps)  # a throw-away twin of shard 0
             probe.run()
