@@ -345,8 +345,8 @@ class Dist:
 
 
 def kernel_interval_ms(env, actions, k2: int, runs: int = 3, all_runs: bool = False):
-    """Average launch interval of the step kernel: k2 launches issued straight through the C ABI (preallocated outputs,
-    no per-step Python work) so the queue never drains, bracketed by ONE pair of HIP events on the launch stream (torch's
+    """Average launch interval of the step kernel: k2 launches issued straight through the C ABI (fe_env_step_traj with
+    preallocated outputs -- the form of the kernel the timed loop launches --, no per-step Python work) so the queue never drains, bracketed by ONE pair of HIP events on the launch stream (torch's
     current stream is the stream the C ABI launches on); the interval = kernel + the ~1.5 us launch boundary.  Uses the
     env's own observation ring (keeps the HBM / MALL regime of the timed region).  Median of `runs` (or all of them)."""
     from finenvs_amd import _lib as _fl
@@ -357,15 +357,18 @@ def kernel_interval_ms(env, actions, k2: int, runs: int = 3, all_runs: bool = Fa
     nb = len(obs_b)
     rew_b = torch.empty((N,), dtype=torch.float64, device=dev)
     done_b = torch.empty((N,), dtype=torch.int32, device=dev)
+    # the same FORM of the kernel as the timed loop launches (its step writes agent.store's action copy too)
+    act_b = torch.empty((N, env.num_assets), dtype=torch.float32, device=dev)
     aptr = [a.data_ptr() for a in actions]
-    fn, h = env._step_fn, env._handle_v
+    fn, h = env._lib.fe_env_step_traj, env._handle_v
+    rp, dp, ap = rew_b.data_ptr(), done_b.data_ptr(), act_b.data_ptr()
     out = []
     for _ in range(runs):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize()
         e0.record()
         for i in range(k2):
-            rc = fn(h, aptr[i % 8], obs_b[i % nb], rew_b.data_ptr(), done_b.data_ptr(), stream)
+            rc = fn(h, aptr[i % 8], obs_b[i % nb], rp, dp, ap, None, None, stream)
         e1.record()
         torch.cuda.synchronize()
         _fl.check(rc)

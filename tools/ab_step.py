@@ -75,10 +75,16 @@ def block(env):
     rew = torch.empty((N,), dtype=torch.float64, device=dev)
     done = torch.empty((N,), dtype=torch.int32, device=dev)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    act_b = torch.empty((N, A), dtype=torch.float32, device=dev)
     torch.cuda.synchronize()
     e0.record()
-    for i in range(K):
-        env._step_fn(env._handle_v, actions[i % 8].data_ptr(), obs_b[i % nbuf], rew.data_ptr(), done.data_ptr(), stream)
+    if os.environ.get("AB_FULL") == "1":  # the full form of the kernel (trajectory action copy), as bench.py's loop launches it
+        for i in range(K):
+            env._lib.fe_env_step_traj(env._handle_v, actions[i % 8].data_ptr(), obs_b[i % nbuf], rew.data_ptr(), done.data_ptr(),
+                                      act_b.data_ptr(), None, None, stream)
+    else:
+        for i in range(K):
+            env._step_fn(env._handle_v, actions[i % 8].data_ptr(), obs_b[i % nbuf], rew.data_ptr(), done.data_ptr(), stream)
     e1.record()
     torch.cuda.synchronize()
     return e0.elapsed_time(e1) / K * 1e3
