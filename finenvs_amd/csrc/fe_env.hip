@@ -198,10 +198,8 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     const bool f32 = env->cfg.obs_is_f32 != 0, single = p.A == 1;
     const bool full = !RESET_ONLY && (p.evaluate || p.run_ret || desc_src || act_store);
-    if (host_flag && full)
-        return fail(FE_ERR_STATE, "fe_env_step_notify: not together with evaluate mode, bound episode statistics or trajectory outputs");
     const void *kern = RESET_ONLY ? kernel_for<true, kLean>(f32, env->vec, single)
-                       : (host_flag ? kernel_for<false, kNotify>(f32, env->vec, single)
+                       : (host_flag ? (full ? kernel_for<false, kFullNotify>(f32, env->vec, single) : kernel_for<false, kNotify>(f32, env->vec, single))
                                     : (full ? kernel_for<false, kFull>(f32, env->vec, single) : kernel_for<false, kLean>(f32, env->vec, single)));
     hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, env->lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");
@@ -445,11 +443,21 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
 
 int fe_env_step_notify(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
                        uint64_t *host_flag, uint64_t seq, void *stream) {
+    return fe_env_step_traj_notify(env, actions, obs, rewards, dones, nullptr, nullptr, nullptr, host_flag, seq, stream);
+}
+
+int fe_env_step_traj_notify(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                            float *actions_store_out, int64_t *obs_src_out, double *obs_pos_out, uint64_t *host_flag,
+                            uint64_t seq, void *stream) {
     if (!env || !actions || !obs || !rewards || !dones || !host_flag) return fail(FE_ERR_ARG, "fe_env_step_notify: null argument");
+    if ((obs_src_out == nullptr) != (obs_pos_out == nullptr))
+        return fail(FE_ERR_ARG, "fe_env_step_traj_notify: obs_src_out and obs_pos_out go together");
+    if (actions_store_out == actions) actions_store_out = nullptr;
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step_notify: state not bound");
     if (env->p.eval_env < 0)
         return fail(FE_ERR_ARG, "fe_env_step_notify: this env has no evaluation env (evaluate mode, or a shard without it)");
-    return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream, nullptr, nullptr, nullptr, host_flag, seq);
+    return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream, obs_src_out, obs_pos_out, actions_store_out,
+                             host_flag, seq);
 }
 
 int fe_host_flag_create(uint64_t **host_flag) {

@@ -10,8 +10,11 @@ namespace {
 // post-step (post-reset) state.
 // FORM: kLean = launches that have none of the optional outputs (evaluate-mode bookkeeping, episode statistics,
 // trajectory descriptors / action copy): their eight pointers never become live scalars; kFull = all of them;
-// kNotify = the lean form + fe_env_step_notify's host flag (and its last-tile-first walk).
-constexpr int kLean = 0, kFull = 1, kNotify = 2;
+// kNotify / kFullNotify = the lean / full form + the host flag of fe_env_step_notify / fe_env_step_traj_notify (and their
+// last-tile-first walk).
+constexpr int kLean = 0, kFull = 1, kNotify = 2, kFullNotify = 3;
+constexpr bool form_is_full(int form) { return form == kFull || form == kFullNotify; }
+constexpr bool form_notifies(int form) { return form == kNotify || form == kFullNotify; }
 template <bool SINGLE, int FORM>
 __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, int A, int e, int a, bool active,
                                              int64_t n, int64_t sl, const SleeveIn &in, float action,
@@ -43,7 +46,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             const int64_t s0c = s0 + W <= L ? s0 : L - W;
             l.src[e] = (in.idx * L + s0c) * rs;
         }
-        if constexpr (FORM == kFull) {
+        if constexpr (form_is_full(FORM)) {
             if (p.desc_src) {  // the returned observation as descriptors, 8 + 8A bytes per env (a trajectory's `states`)
                 p.desc_pos[sl] = s.pos_obs;
                 if (a == 0) p.desc_src[n] = l.src[e];
@@ -79,7 +82,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             }
         }
         p.spot0[n] = s0;
-        if constexpr (FORM == kFull) {
+        if constexpr (form_is_full(FORM)) {
             if (p.evaluate) {  // TSE:523-536
                 const bool term = p.terminated[n] != 0;
                 if (term) rew = 0.0;
@@ -92,13 +95,13 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
         }
         rew_out[n] = rew;
         done_out[n] = any ? 1 : 0;
-        if constexpr (FORM == kNotify) {
+        if constexpr (form_notifies(FORM)) {
             // fe_env_step_notify: the host polls this instead of copying dones back after the launch (TSE:510); a relaxed
             // system-scope store -- the host reads nothing else of this launch through it
             if (n == p.eval_env)
                 __hip_atomic_store(p.host_flag, (p.flag_seq << 1) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
-        if constexpr (FORM == kFull) {
+        if constexpr (form_is_full(FORM)) {
             if (p.run_ret) {  // PPO_agent.py:120-132 without its per-step host sync
                 float cr = (float)((double)p.run_ret[n] + rew);
                 if (any) {
@@ -345,7 +348,7 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
     lds_barrier();
     // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
     bool act1, act2;
-    constexpr bool rev = FORM == kNotify;
+    constexpr bool rev = form_notifies(FORM);
     const int64_t n_nxt = pipe_env_of(p, EB, e, tile_at(p, k + 1, rev), act1);
     const int64_t n_nn = pipe_env_of(p, EB, e, tile_at(p, k + 2, rev), act2);
     load_body(p, 1, 0, act1, n_nxt, ps.idx1, ps.spot1, ps.in_nxt);
@@ -399,7 +402,7 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
         }
     } else if constexpr (!SINGLE) {
         // multi-asset tiles stream hundreds of KiB each: phase 1 is <1 % of a tile, no pipelining needed
-        constexpr bool rev = FORM == kNotify;
+        constexpr bool rev = form_notifies(FORM);
         for (int64_t k = 0, tile; (tile = tile_at(p, k, rev)) < p.num_tiles; ++k) {
             const int64_t n0 = tile * EB;
             const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
@@ -416,7 +419,7 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
         // (phase 2, the long part), the state + bar gathers of tile i+1 and the index loads of tile
         // i+2 are already in flight, so only the very first tile pays phase 1's two dependent
         // memory round trips.
-        constexpr bool rev = FORM == kNotify;
+        constexpr bool rev = form_notifies(FORM);
         int64_t tile = tile_at(p, 0, rev);
         PipeState ps;
         ps.action_cur = 0.0f; ps.action_nxt = 0.0f; ps.action_nn = 0.0f;

@@ -515,15 +515,16 @@ class TimeSeriesEnv:
             dones = dones_out
             if dones.dtype is not torch.int32 or dones.numel() != N or not dones.is_contiguous() or dones.device != self._dev:
                 raise ValueError("dones_out must be a contiguous int32 tensor of num_envs elements on the env's device")
-        notify = (self._flag is not None and descriptors_out is None and actions_out is None
-                  and not getattr(self, "_stats_bound", False))
+        notify = self._flag is not None
         if notify:
             self._flag_seq = seq = (self._flag_seq + 1) & 0x3FFFFFFFFFFFFFFF
-            rc = self._lib.fe_env_step_notify(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
-                                              dones.data_ptr(), self._flag, seq, self._stream())
-        elif descriptors_out is None and actions_out is None:
-            rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
-                               self._stream())
+        if descriptors_out is None and actions_out is None:
+            if notify:
+                rc = self._lib.fe_env_step_notify(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
+                                                  dones.data_ptr(), self._flag, seq, self._stream())
+            else:
+                rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
+                                   self._stream())
         else:
             src = pos = None
             if descriptors_out is not None:
@@ -534,10 +535,14 @@ class TimeSeriesEnv:
             if actions_out is not None and (actions_out.dtype is not torch.float32 or actions_out.numel() != N * A
                                             or not actions_out.is_contiguous() or actions_out.device != self._dev):
                 raise ValueError("actions_out must be a contiguous float32 tensor of num_envs x num_assets elements on the env's device")
-            rc = self._lib.fe_env_step_traj(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
-                                            actions_out.data_ptr() if actions_out is not None else None,
-                                            src.data_ptr() if src is not None else None,
-                                            pos.data_ptr() if pos is not None else None, self._stream())
+            outs = (actions_out.data_ptr() if actions_out is not None else None, src.data_ptr() if src is not None else None,
+                    pos.data_ptr() if pos is not None else None)
+            if notify:
+                rc = self._lib.fe_env_step_traj_notify(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
+                                                       dones.data_ptr(), *outs, self._flag, seq, self._stream())
+            else:
+                rc = self._lib.fe_env_step_traj(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
+                                                dones.data_ptr(), *outs, self._stream())
         self._last_descriptors = descriptors_out  # None: the observation just returned was not recorded
         self._stepped = True
         self._generation += 1

@@ -29,11 +29,9 @@ class EpisodeStats:
         self._eval = torch.zeros((2,), dtype=torch.float32, device=dev)
         _lib.check(env._lib.fe_env_bind_stats(env._handle, self.running_returns.data_ptr(), self._acc.data_ptr(),
                                               self._eval.data_ptr()))
-        env._stats_bound = True  # (step() then reads the eval env's done flag the plain way: fe_env_step_notify is the lean kernel)
 
     def close(self) -> None:
         _lib.check(self.env._lib.fe_env_bind_stats(self.env._handle, None, None, None))
-        self.env._stats_bound = False
 
     def read(self, reset: bool = True) -> Dict[str, float]:
         """One D2H copy: what PPOAgent.log_progress prints (PPO_agent.py:146-163)."""

@@ -127,11 +127,14 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
  * fe_host_flag_create, system scope -- a few microseconds after the launch starts; the host polls the flag until it
  * carries `seq` (any value that changes per call) and can issue the next launches while this one is still streaming.
  * Tile order is the only difference to fe_env_step: results are identical.  FE_ERR_ARG if the env has no evaluation env
- * (evaluate mode, or a shard that does not own it); FE_ERR_STATE while episode statistics are bound (fe_env_bind_stats:
- * this is the lean kernel -- use fe_env_step and read dones[eval_env] there).
+ * (evaluate mode, or a shard that does not own it).  fe_env_step_traj_notify is the same with fe_env_step_traj's optional
+ * trajectory outputs (each may be NULL); bound episode statistics are updated by both.
  */
 int fe_env_step_notify(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
                        uint64_t *host_flag, uint64_t seq, void *stream);
+int fe_env_step_traj_notify(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
+                            float *actions_store_out, int64_t *obs_src_out, double *obs_pos_out, uint64_t *host_flag,
+                            uint64_t seq, void *stream);
 /* A host-resident, device-visible, coherent 8-byte flag for fe_env_step_notify (TSE:510 is the host read it serves); zeroed. */
 int fe_host_flag_create(uint64_t **host_flag);
 int fe_host_flag_destroy(uint64_t *host_flag);

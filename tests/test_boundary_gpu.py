@@ -324,16 +324,36 @@ def test_step_notify_equals_step_and_reports_the_eval_env_early(fe, fo, N, A, W,
         for x, y in ((a_env.cash, b_env.cash), (a_env.margin, b_env.margin), (a_env._spot0, b_env._spot0), (a_env.env_indices, b_env.env_indices)):
             assert torch.equal(x, y)
     assert seen_done >= 1  # 30-bar days: the evaluation env finished at least once (and redrew its day identically)
-    # no evaluation env -> refused; episode statistics bound -> refused (this is the lean kernel)
+    # no evaluation env -> refused
     ev = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, evaluate=True, obs_dtype=dt)
     rc = lib.fe_env_step_notify(ev._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), flag, 1, st)
     assert rc == _lib.FE_ERR_ARG and b"evaluation env" in lib.fe_last_error()
+    # with trajectory outputs and bound episode statistics: the full form + flag, again equal to the plain calls
     from finenvs_amd.stats import EpisodeStats
 
-    stats = EpisodeStats(a_env)
-    rc = lib.fe_env_step_notify(a_env._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), flag, 2, st)
-    assert rc == _lib.FE_ERR_STATE
-    stats.close()
+    sa, sb = EpisodeStats(a_env), EpisodeStats(b_env)
+    src = torch.empty((N,), dtype=torch.int64, device="cuda")
+    pos = torch.empty((N, A), dtype=torch.float64, device="cuda")
+    aout = torch.empty((N, A), dtype=torch.float32, device="cuda")
+    src2, pos2, aout2 = torch.empty_like(src), torch.empty_like(pos), torch.empty_like(aout)
+    for k in range(100, 140):
+        a = (torch.rand((N, A), generator=g, device="cuda") * 2 - 1).float()
+        _lib.check(lib.fe_env_step_traj_notify(a_env._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(),
+                                               aout.data_ptr(), src.data_ptr(), pos.data_ptr(), flag, 5000 + k, st))
+        o2, r2, d2, _ = b_env.step(a, descriptors_out=(src2, pos2), actions_out=aout2)
+        torch.cuda.synchronize()
+        assert word.value == ((5000 + k) << 1 | int(done[-1]))
+        assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(done, d2)
+        assert torch.equal(src, src2) and torch.equal(pos, pos2) and torch.equal(aout, aout2) and torch.equal(aout, a)
+        assert torch.equal(sa.running_returns, sb.running_returns)
+    ra, rb = sa.read(), sb.read()
+    assert ra["num_training_episodes"] == rb["num_training_episodes"] > 0
+    assert ra["evaluation_return"] == rb["evaluation_return"] and ra["num_evaluation_episodes"] == rb["num_evaluation_episodes"]
+    # the finished-episode sums are atomics: the reversed tile walk adds them in another order (last-ulp differences)
+    assert ra["mean_training_return"] == pytest.approx(rb["mean_training_return"], rel=1e-12)
+    assert ra["std_dev_training_return"] == pytest.approx(rb["std_dev_training_return"], rel=1e-10)
+    sa.close()
+    sb.close()
     torch.cuda.synchronize()
     _lib.check(lib.fe_host_flag_destroy(flag))
 
@@ -341,7 +361,7 @@ def test_step_notify_equals_step_and_reports_the_eval_env_early(fe, fo, N, A, W,
 def test_default_mode_polls_the_host_flag_and_keeps_the_reference_rng_stream(fe, fo):
     """redraw="torch" (the class default): step() decides the evaluation env's redraw from the host flag; the draws it
     takes from torch's global generator are the ones the plain dones[-1].item() path takes (same seed -> same day
-    sequence, same generator state afterwards), also while episode statistics force the plain path."""
+    sequence, same generator state afterwards)."""
     from finenvs_amd.data import synthetic
     from finenvs_amd.stats import EpisodeStats
 
@@ -351,7 +371,10 @@ def test_default_mode_polls_the_host_flag_and_keeps_the_reference_rng_stream(fe,
         torch.manual_seed(99)
         env = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=4, num_envs=9)
         assert env.redraw == "torch" and env._flag is not None
-        stats = EpisodeStats(env) if plain else None  # bound statistics -> step() uses fe_env_step + .item()
+        stats = None
+        if plain:  # the plain path: fe_env_step + the reference's dones[-1].item()
+            env._lib.fe_host_flag_destroy(env._flag)
+            env._flag = None
         g = torch.Generator(device="cuda").manual_seed(1)
         days = []
         for _ in range(120):

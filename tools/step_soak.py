@@ -48,7 +48,7 @@ for case in range(cases):
     f32 = bool(rng.integers(0, 2))
     evaluate = bool(rng.integers(0, 4) == 0)
     balance = float(rng.choice([10000, 2000, 600, 150]))
-    mode = str(rng.choice(["plain", "traj", "stats", "notify"])) if not evaluate else str(rng.choice(["plain", "traj"]))
+    mode = str(rng.choice(["plain", "traj", "stats", "notify", "trajnotify"])) if not evaluate else str(rng.choice(["plain", "traj"]))
     prices, day_id, _ = synthetic.synthetic_series(days, A, bars, int(rng.integers(0, 10**6)), drop)
     try:
         P, LR, *_ = fo.tables_from_series(prices, day_id, W)
@@ -66,7 +66,7 @@ for case in range(cases):
     lib = env._lib
     stats = EpisodeStats(env) if mode == "stats" else None
     flag = None
-    if mode == "notify":
+    if mode in ("notify", "trajnotify"):
         flag = C.c_void_p()
         _lib.check(lib.fe_host_flag_create(C.byref(flag)))
         word = C.c_uint64.from_address(flag.value)
@@ -86,6 +86,20 @@ for case in range(cases):
             o, r, d, i = env.step(ad, descriptors_out=(src, pos), actions_out=aout)
             bits(t2n(aout), a.numpy(), f"case {case} step {t} action copy")
             bits(t2n(env.render(src, pos)), o_r, f"case {case} step {t} rendered descriptors")
+        elif mode == "trajnotify":
+            o = torch.empty((N, W, 5 * A), dtype=env.obs_dtype, device=dev)
+            r = torch.empty((N,), dtype=torch.float64, device=dev)
+            d = torch.empty((N,), dtype=torch.int32, device=dev)
+            src = torch.empty((N,), dtype=torch.int64, device=dev)
+            pos = torch.empty((N, A), dtype=torch.float64, device=dev)
+            aout = torch.empty((N, A), dtype=torch.float32, device=dev)
+            _lib.check(lib.fe_env_step_traj_notify(env._handle, ad.data_ptr(), o.data_ptr(), r.data_ptr(), d.data_ptr(), aout.data_ptr(),
+                                                   src.data_ptr(), pos.data_ptr(), flag, t + 1, torch.cuda.current_stream().cuda_stream))
+            torch.cuda.synchronize()
+            assert word.value == ((t + 1) << 1 | int(d_r[-1])), f"case {case} step {t}: flag {word.value:#x}"
+            bits(t2n(aout), a.numpy(), f"case {case} step {t} action copy")
+            bits(t2n(env.render(src, pos)), o_r, f"case {case} step {t} rendered descriptors")
+            i = {}
         elif mode == "notify":
             o = torch.empty((N, W, 5 * A), dtype=env.obs_dtype, device=dev)
             r = torch.empty((N,), dtype=torch.float64, device=dev)
