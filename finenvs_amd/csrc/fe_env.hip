@@ -977,8 +977,12 @@ int fe_traj_returns(const double *rewards, const int32_t *dones, const float *va
         return fail(FE_ERR_ARG, "fe_traj_returns: bad argument");
     DeviceGuard guard(device_of(rewards));
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
-    hipLaunchKernelGGL(fe_traj_returns_kernel, dim3(grid_for(N)), dim3(kBlock), 0, (hipStream_t)stream, rewards, dones,
-                       values, last_values, T, N, (float)gamma, returns, advantages);
+    if (N >= (1 << 19))
+        hipLaunchKernelGGL(fe_traj_returns_kernel<1>, dim3(grid_for(N)), dim3(kBlock), 0, (hipStream_t)stream, rewards, dones,
+                           values, last_values, T, N, (float)gamma, returns, advantages);
+    else
+        hipLaunchKernelGGL(fe_traj_returns_kernel<4>, dim3(grid_for(N)), dim3(kBlock), 0, (hipStream_t)stream, rewards, dones,
+                           values, last_values, T, N, (float)gamma, returns, advantages);
     hipError_t he = hipGetLastError();
     if (he != hipSuccess) return hip_fail(he, "fe_traj_returns launch");
     return FE_OK;

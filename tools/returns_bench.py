@@ -6,10 +6,19 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from finenvs_amd import _lib  # noqa: E402
 from finenvs_amd.trajectory import TrajectoryBuffer  # noqa: E402
+
+if len(sys.argv) > 1:  # an experiment build by its tag (finenvs_amd.csrc.build.build_variant)
+    VARIANT = _lib.load(os.path.join(os.path.dirname(_lib.LIB_PATH), "variants", f"libfinenvs_amd.{sys.argv[1]}.so"))
+    print("library:", sys.argv[1])
+else:
+    VARIANT = None
 
 for T, N in ((16, 65536), (128, 65536), (16, 1048576), (128, 1048576), (512, 1048576)):
     buf = TrajectoryBuffer(T, N, 1, device="cuda:0")
+    if VARIANT is not None:
+        buf._lib = VARIANT
     buf.rewards.normal_(); buf.dones.zero_(); buf.t = T
     vals = torch.randn((T, N), device="cuda:0"); last = torch.randn((N,), device="cuda:0")
     buf.returns_and_advantages(vals, last)
