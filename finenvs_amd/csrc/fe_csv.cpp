@@ -23,7 +23,10 @@
 #include <unistd.h>
 
 #include <charconv>
+#include <functional>
+#include <thread>
 #include <unordered_map>
+#include <vector>
 
 #include "finenvs_amd.h"
 
@@ -134,6 +137,75 @@ inline int64_t date_join_key(const char *b, const char *e) {
 constexpr int64_t kOpen = (9 * 60 + 30) * 60;   // 09:30:00, first bar kept
 constexpr int64_t kLast = (15 * 60 + 59) * 60;  // 15:59:00, last bar kept (between_time is inclusive)
 
+// One thread's share of the file: whole lines [begin, end), parsed into its own vectors.  Parsing stops at the piece's
+// first malformed line (error != 0; the rows before it are kept, so that the stitching pass can report the first error
+// of the FILE with its absolute line number).
+struct Piece {
+    const char *begin = nullptr, *end = nullptr;
+    std::vector<double> prices;   // 4 per kept row
+    std::vector<uint64_t> key;    // date join key per kept row
+    std::vector<int64_t> sec;     // second of day per kept row
+    int64_t lines = 0;            // lines in the piece (all of them, or up to and including the malformed one)
+    int error = 0;                // 1 = too few fields, 2 = bad time, 3 = bad number
+    int error_arg = 0;            // field count / column
+    int64_t error_line = 0;       // 1-based within the piece
+};
+
+void parse_piece(Piece &pc, bool market_hours_only) {
+    const size_t guess = (size_t)(pc.end - pc.begin) / 40 + 16;  // a bar line is ~45-60 bytes
+    pc.prices.reserve(guess * 4);
+    pc.key.reserve(guess);
+    pc.sec.reserve(guess);
+    const char *prev_date = nullptr;
+    size_t prev_len = 0;
+    uint64_t prev_key = 0;
+    const char *p = pc.begin, *end = pc.end;
+    while (p < end) {
+        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
+        const char *le = nl ? nl : end;
+        ++pc.lines;
+        const char *lb = trim_l(p, le);
+        const char *lt = trim_r(lb, le);
+        p = nl ? nl + 1 : end;
+        if (lb == lt) continue;  // blank line
+        // split the first six fields
+        const char *fb[7], *fe_[7];
+        int nf = 0;
+        const char *q = lb;
+        while (nf < 7) {
+            const char *c = (const char *)memchr(q, ',', (size_t)(lt - q));
+            fb[nf] = trim_l(q, c ? c : lt);
+            fe_[nf] = trim_r(fb[nf], c ? c : lt);
+            ++nf;
+            if (!c) break;
+            q = c + 1;
+        }
+        auto stop = [&](int code, int arg) {
+            pc.error = code; pc.error_arg = arg; pc.error_line = pc.lines;
+        };
+        if (nf < 6) { stop(1, nf); return; }
+        const int64_t sec = parse_time(fb[1], fe_[1]);
+        if (sec < 0) { stop(2, 0); return; }
+        if (market_hours_only && (sec < kOpen || sec > kLast)) continue;
+        double v[4];
+        for (int k = 0; k < 4; ++k) {
+            const char *b = fb[2 + k], *e = fe_[2 + k];
+            if (b < e && *b == '+') ++b;
+            auto r = std::from_chars(b, e, v[k]);
+            if (r.ec != std::errc() || r.ptr != e) { stop(3, 3 + k); return; }
+        }
+        pc.prices.insert(pc.prices.end(), v, v + 4);
+        // rows of one date are consecutive in every real file: compare the date text with the previous row's first
+        const size_t dlen = (size_t)(fe_[0] - fb[0]);
+        if (!(prev_date && dlen == prev_len && memcmp(prev_date, fb[0], dlen) == 0)) {
+            prev_key = (uint64_t)date_join_key(fb[0], fe_[0]);
+            prev_date = fb[0]; prev_len = dlen;
+        }
+        pc.key.push_back(prev_key);
+        pc.sec.push_back(sec);
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -159,69 +231,79 @@ int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_onl
         return fe_set_error(FE_ERR_ARG, "fe_csv_read: bad argument");
     Mapped m(path);
     if (!m.ok) return fe_set_error(FE_ERR_ARG, "fe_csv_read: cannot open %s", path);
+    // Parsing is independent per line: the file is cut at line boundaries into one piece per thread (>= 4 MiB each, at
+    // most 8), every piece is parsed into its own vectors, and a sequential pass stitches them together -- row order,
+    // day ids in order of first appearance, the first error in FILE order -- exactly as one pass over the file would.
+    unsigned want = std::thread::hardware_concurrency();
+    if (want == 0) want = 1;
+    if (want > 8) want = 8;
+    size_t pieces = m.n / (4u << 20);
+    if (pieces < 1) pieces = 1;
+    if (pieces > want) pieces = want;
+    std::vector<Piece> piece(pieces);
+    {
+        const char *cut = m.p, *end = m.p + m.n;
+        for (size_t i = 0; i < pieces; ++i) {
+            piece[i].begin = cut;
+            const char *target = i + 1 == pieces ? end : m.p + m.n / pieces * (i + 1);
+            if (target < cut) target = cut;
+            if (i + 1 < pieces) {
+                const char *nl = (const char *)memchr(target, '\n', (size_t)(end - target));
+                cut = nl ? nl + 1 : end;
+            } else {
+                cut = end;
+            }
+            piece[i].end = cut;
+        }
+    }
+    if (pieces == 1) {
+        parse_piece(piece[0], market_hours_only != 0);
+    } else {
+        std::vector<std::thread> workers;
+        for (size_t i = 1; i < pieces; ++i) workers.emplace_back(parse_piece, std::ref(piece[i]), market_hours_only != 0);
+        parse_piece(piece[0], market_hours_only != 0);
+        for (auto &w : workers) w.join();
+    }
     std::unordered_map<uint64_t, int64_t> days;  // date key -> id in order of first appearance
-    int64_t rows = 0, line_no = 0;
-    const char *prev_date = nullptr;
-    size_t prev_len = 0;
+    int64_t rows = 0, lines_before = 0;
+    bool have_prev = false;
     uint64_t prev_key = 0;
     int64_t prev_id = 0;
-    const char *p = m.p, *end = m.p + m.n;
-    while (p < end) {
-        const char *nl = (const char *)memchr(p, '\n', (size_t)(end - p));
-        const char *le = nl ? nl : end;
-        ++line_no;
-        const char *lb = trim_l(p, le);
-        const char *lt = trim_r(lb, le);
-        p = nl ? nl + 1 : end;
-        if (lb == lt) continue;  // blank line
-        // split the first six fields
-        const char *fb[7], *fe_[7];
-        int nf = 0;
-        const char *q = lb;
-        while (nf < 7) {
-            const char *c = (const char *)memchr(q, ',', (size_t)(lt - q));
-            fb[nf] = trim_l(q, c ? c : lt);
-            fe_[nf] = trim_r(fb[nf], c ? c : lt);
-            ++nf;
-            if (!c) break;
-            q = c + 1;
-        }
-        if (nf < 6) return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld has %d fields, need >= 6", path, (long long)line_no, nf);
-        const int64_t sec = parse_time(fb[1], fe_[1]);
-        if (sec < 0) return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld: bad time", path, (long long)line_no);
-        if (market_hours_only && (sec < kOpen || sec > kLast)) continue;
-        if (rows >= capacity) return fe_set_error(FE_ERR_ARG, "fe_csv_read: capacity %lld too small", (long long)capacity);
-        for (int k = 0; k < 4; ++k) {
-            double v;
-            const char *b = fb[2 + k], *e = fe_[2 + k];
-            if (b < e && *b == '+') ++b;
-            auto r = std::from_chars(b, e, v);
-            if (r.ec != std::errc() || r.ptr != e)
-                return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld: bad number in column %d", path, (long long)line_no, 3 + k);
-            prices[rows * 4 + k] = v;
-        }
-        // rows of one date are consecutive in every real file: compare the date text with the previous row's first
-        uint64_t key;
-        int64_t id;
-        const size_t dlen = (size_t)(fe_[0] - fb[0]);
-        if (prev_date && dlen == prev_len && memcmp(prev_date, fb[0], dlen) == 0) {
-            key = prev_key;
-            id = prev_id;
-        } else {
-            key = (uint64_t)date_join_key(fb[0], fe_[0]);
-            auto it = days.find(key);
-            if (it == days.end()) {
-                id = (int64_t)days.size();
-                days.emplace(key, id);
-            } else {
-                id = it->second;
+    for (size_t i = 0; i < pieces; ++i) {
+        const Piece &pc = piece[i];
+        const int64_t n_ok = (int64_t)pc.sec.size();
+        // (a piece's malformed line comes after all of its kept rows, so an overflowing row is the earlier event)
+        if (rows + n_ok > capacity) return fe_set_error(FE_ERR_ARG, "fe_csv_read: capacity %lld too small", (long long)capacity);
+        if (n_ok) {
+            memcpy(prices + rows * 4, pc.prices.data(), sizeof(double) * 4 * (size_t)n_ok);
+            memcpy(second_of_day + rows, pc.sec.data(), sizeof(int64_t) * (size_t)n_ok);
+            for (int64_t r = 0; r < n_ok; ++r) {
+                const uint64_t key = pc.key[r];
+                int64_t id;
+                if (have_prev && key == prev_key) {  // rows of one date are consecutive in every real file
+                    id = prev_id;
+                } else {
+                    auto it = days.find(key);
+                    if (it == days.end()) {
+                        id = (int64_t)days.size();
+                        days.emplace(key, id);
+                    } else {
+                        id = it->second;
+                    }
+                    have_prev = true; prev_key = key; prev_id = id;
+                }
+                day_id[rows + r] = id;
+                if (date_key) date_key[rows + r] = (int64_t)key;
             }
-            prev_date = fb[0]; prev_len = dlen; prev_key = key; prev_id = id;
+            rows += n_ok;
         }
-        day_id[rows] = id;
-        if (date_key) date_key[rows] = (int64_t)key;
-        second_of_day[rows] = sec;
-        ++rows;
+        if (pc.error != 0) {
+            const long long line = (long long)(lines_before + pc.error_line);
+            if (pc.error == 1) return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld has %d fields, need >= 6", path, line, pc.error_arg);
+            if (pc.error == 2) return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld: bad time", path, line);
+            return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s line %lld: bad number in column %d", path, line, pc.error_arg);
+        }
+        lines_before += pc.lines;
     }
     return rows;
 }

@@ -86,6 +86,54 @@ def test_errors_are_loud(tmp_path):
     assert prices.shape == (0, 4)
 
 
+def test_multi_piece_parse_equals_pandas_and_reports_the_first_error_in_file_order(tmp_path):
+    """Files beyond 8 MiB are cut at line boundaries and parsed by several threads (fe_csv.cpp); the stitched result, the
+    day numbering across the cuts, the absolute line number of the FIRST malformed line and the capacity check must be
+    what a single pass gives."""
+    import ctypes as C
+
+    from finenvs_amd import _lib
+    from finenvs_amd._lib import FinEnvsNativeError
+
+    prices, day_id, minute = synthetic.synthetic_series(700, 1, 390, 3)   # ~18.7 MB with the pre-market rows: 4 pieces
+    p = str(tmp_path / "data" / "BIG" / "dummy.csv")
+    synthetic.write_csv(p, prices, day_id, minute, 0, premarket_rows=60)
+    assert os.path.getsize(p) > 16 * (1 << 20)
+    a = loader.read_csv_series(p)
+    b = loader.read_csv_series_pandas(p)
+    assert a[0].shape[0] == 700 * 390
+    assert_bits(a[0], b[0]); assert_bits(a[1], b[1]); assert_bits(a[2], b[2])
+    assert a[1].tolist() == np.repeat(np.arange(700), 390).tolist()  # day ids run on across the cuts
+
+    lines = open(p).read().split("\n")
+    n_lines = len(lines) - 1
+    lib = _lib.load()
+    # two malformed lines, one in the last piece and one in the third: the earlier one is reported, with its absolute number
+    bad_late, bad_early = n_lines - 50, int(n_lines * 0.6)
+    broken = list(lines)
+    broken[bad_late] = "2020-01-02,10:00,1,2"
+    while not ("09:30" <= broken[bad_early].split(",")[1][:5] <= "15:59"):  # (a pre-market row is dropped before its numbers are read)
+        bad_early += 1
+    f = broken[bad_early].split(",")
+    f[2] = "x" + f[2]  # the Open field
+    broken[bad_early] = ",".join(f)
+    q = str(tmp_path / "data" / "BIG" / "broken.csv")
+    open(q, "w").write("\n".join(broken))
+    with pytest.raises(FinEnvsNativeError, match=rf"line {bad_early + 1}: bad number in column 3"):
+        loader.read_csv_series(q)
+    broken[bad_early] = lines[bad_early]
+    open(q, "w").write("\n".join(broken))
+    with pytest.raises(FinEnvsNativeError, match=rf"line {bad_late + 1} has 4 fields"):
+        loader.read_csv_series(q)
+    # capacity: exactly enough is fine, one row less is refused (whichever piece the overflowing row falls into)
+    rows = 700 * 390
+    for cap, ok in ((rows, True), (rows - 1, False), (rows // 2, False)):
+        pr = np.empty((max(cap, 1), 4)); d = np.empty(max(cap, 1), np.int64); k = np.empty(max(cap, 1), np.int64); sc = np.empty(max(cap, 1), np.int64)
+        rc = lib.fe_csv_read(os.fsencode(p), cap, 1, pr.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p),
+                             k.ctypes.data_as(C.c_void_p), sc.ctypes.data_as(C.c_void_p))
+        assert (rc == rows) if ok else (rc < 0 and b"capacity" in lib.fe_last_error())
+
+
 def test_native_reader_reproduces_reference_frames(tmp_path):
     g = load_golden("tables_ragged.npz")
     prices, day_id, minute = synthetic.synthetic_series(7, 1, 40, 77, 0.10)

@@ -24,8 +24,11 @@ int main(int argc, char **argv) {
     return 0;
 }
 CPP
-g++ -g -O1 -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer -I $ROOT/include \
+g++ -g -O1 -std=c++17 -pthread -fsanitize=address,undefined -fno-omit-frame-pointer -I $ROOT/include \
     $OUT/csv_main.cpp $ROOT/finenvs_amd/csrc/fe_csv.cpp -o $OUT/csv_asan
+# the reader parses files beyond 8 MiB on several threads: the same main under ThreadSanitizer
+g++ -g -O1 -std=c++17 -pthread -fsanitize=thread -fno-omit-frame-pointer -I $ROOT/include \
+    $OUT/csv_main.cpp $ROOT/finenvs_amd/csrc/fe_csv.cpp -o $OUT/csv_tsan
 # inputs: well-formed, ragged, truncated, garbage
 python3 - "$OUT" <<'PY'
 import os, sys
@@ -39,8 +42,14 @@ open(f"{out}/garbage.csv", "wb").write(bytes(range(256)) * 40)
 open(f"{out}/empty.csv", "w").close()
 open(f"{out}/commas.csv", "w").write(",,,,,,\n,,\n")
 open(f"{out}/long.csv", "w").write("2020-01-02,10:00," + "9" * 400 + ",1,1,1,1\n")
+# 24 MB: several pieces; and the same with a malformed line far into it
+big = [f"2020-{1 + (i // 11700) % 12:02d}-{1 + (i // 390) % 28:02d},{9 + (i % 390 + 30) // 60:02d}:{(i % 390 + 30) % 60:02d}:00,{100 + i % 7}.25,{101 + i % 7}.5,{99 + i % 7}.125,{100 + i % 7}.75,{i}" for i in range(420000)]
+open(f"{out}/big.csv", "w").write("\n".join(big) + "\n")
+big[333333] = "2020-01-02,10:00,1,2"
+open(f"{out}/bigbad.csv", "w").write("\n".join(big) + "\n")
 PY
-$OUT/csv_asan $OUT/ok.csv $OUT/nonl.csv $OUT/trunc.csv $OUT/garbage.csv $OUT/empty.csv $OUT/commas.csv $OUT/long.csv $OUT/missing.csv 2>&1 | grep -v "^fe_csv" || true
+$OUT/csv_asan $OUT/ok.csv $OUT/nonl.csv $OUT/trunc.csv $OUT/garbage.csv $OUT/empty.csv $OUT/commas.csv $OUT/long.csv $OUT/missing.csv $OUT/big.csv $OUT/bigbad.csv 2>&1 | grep -v "^fe_csv" || true
+$OUT/csv_tsan $OUT/ok.csv $OUT/big.csv $OUT/bigbad.csv 2>&1 | grep -v "^fe_csv" || true
 # the oracle under ASan/UBSan: replay the golden suite against the instrumented library
 cd $ROOT
 ASAN_OPTIONS=detect_leaks=0 LD_PRELOAD=$(gcc -print-file-name=libasan.so) FE_ORACLE_LIB=$OUT/libfe_oracle.so \
