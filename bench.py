@@ -376,6 +376,14 @@ def kernel_interval_ms(env, actions, k2: int, runs: int = 3, all_runs: bool = Fa
     return out if all_runs else statistics.median(out)
 
 
+def launches_per_run(env, actions, steps: int) -> int:
+    """How many back-to-back launches one HIP-event pair brackets in kernel_interval_ms: at least `steps` and 20, and enough
+    for ~10 ms of GPU time (at most 400) -- a train of 20 launches of a 30 us kernel is dominated by its first launches, which
+    start on an idle GPU whose XCDs wake up staggered, and would overstate the launch interval by ~5 %."""
+    est_ms = kernel_interval_ms(env, actions, 8, runs=1)
+    return int(min(400, max(20, steps, round(10.0 / max(est_ms, 1e-6)))))
+
+
 def auto_repeats(repeats: int, steps: int, est_step_s: float) -> int:
     if repeats > 0:
         return repeats
@@ -421,7 +429,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         as_allocated = None
         if not args.no_audition:
             env.reset()
-            k_aa = min(max(steps, 20), 400)
+            k_aa = launches_per_run(env, actions, steps)
             kernel_interval_ms(env, actions, k_aa, runs=1)  # discarded: clocks, tables and state warm before anything is compared
             as_allocated = {"kernel_ms": kernel_interval_ms(env, actions, k_aa, runs=3)}
             env.audition_ring(AUDITION_EXTRA)
@@ -543,7 +551,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
 
     # Kernel duration for the roofline (kernel_interval_ms): launches issued straight through the C ABI, one pair of
     # HIP events on the launch stream around them.
-    k2 = min(max(steps, 20), 400)
+    k2 = launches_per_run(env, actions, steps)
     kern = kernel_interval_ms(env, actions, k2, runs=3, all_runs=True)
     kern_ms = statistics.median(kern)
 
@@ -627,7 +635,7 @@ def two_stream_leg(args, steps: int):
         acts = [(torch.rand((n, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
         env.reset()
         parts.append((env, acts, torch.empty((n,), dtype=torch.float64, device=dev), torch.empty((n,), dtype=torch.int32, device=dev)))
-    k2 = min(max(steps, 20), 400)
+    k2 = max(min(max(steps, 20), 400), 200)  # (a 27 us step: 200 launch pairs ~ 5 ms per run)
     times = []
     for rep in range(4):
         torch.cuda.synchronize()
@@ -825,7 +833,7 @@ def main():
     if not D.multi and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
         fused = fused_rollout_legs(args)
         try:
-            refsem = reference_semantics_leg(args, args.steps)
+            refsem = reference_semantics_leg(args, max(args.steps, 200))
         except Exception as exc:  # noqa: BLE001
             refsem = {"error": f"{type(exc).__name__}: {exc}"}
         try:
