@@ -484,8 +484,9 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     def fence():
         traj.drain()  # outstanding gathers belong to the timed region
         torch.cuda.synchronize()
-        D.barrier()
-        torch.cuda.synchronize()
+        if D.dist is not None:  # (one process: there is nobody to wait for and nothing the barrier could have queued)
+            D.barrier()
+            torch.cuda.synchronize()
 
     trace = os.environ.get("FE_BENCH_TRACE") == "1"  # stderr: where a timed block's wall time goes (host issue / drain / fence)
 
