@@ -104,6 +104,7 @@ struct Params {
     float *act_store;    // optional (fe_env_step_traj): the actions, copied into a trajectory slot
     unsigned long long *host_flag;  // optional (fe_env_step_notify): host memory that learns early whether the eval env finished
     unsigned long long flag_seq;
+    unsigned int *ticket;           // evaluate-mode envs: workgroups-finished counter of the notify form (env-owned, zero between launches)
     int64_t N, D, L;
     int64_t num_tiles;
     int64_t eval_env;

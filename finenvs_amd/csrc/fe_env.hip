@@ -77,6 +77,7 @@ struct fe_env {
     int tile_override, grid_override, rollout_tile_override;  // fe_env_set_launch (tuning), 0 = automatic
     int device;           // HIP device the tables live on; every launch runs there
     double *owned_logret; // log-return table computed by fe_env_create(logret = NULL), else null
+    unsigned int *ticket; // evaluate mode: 4 bytes of device memory for the notify form's last-workgroup detection
 };
 
 // Makes the env's device current for the duration of a call and restores the caller's device
@@ -330,10 +331,19 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
     env->bound = false;
     env->device = dev;
     env->owned_logret = nullptr;
+    env->ticket = nullptr;
+    if (cfg->evaluate) {
+        if ((he = hipMalloc(&env->ticket, sizeof(unsigned int))) != hipSuccess || (he = hipMemset(env->ticket, 0, sizeof(unsigned int))) != hipSuccess) {
+            if (env->ticket) (void)hipFree(env->ticket);
+            delete env;
+            return hip_fail(he, "fe_env_create: hipMalloc(ticket)");
+        }
+    }
     if (!logret) {
         // logret = NULL: compute the table from the prices (the one allocation this library owns)
         const int64_t tuples = cfg->D * cfg->L * (int64_t)cfg->A;
         if ((he = hipMalloc(&env->owned_logret, (size_t)tuples * 32)) != hipSuccess) {
+            if (env->ticket) (void)hipFree(env->ticket);
             delete env;
             return hip_fail(he, "fe_env_create: hipMalloc(logret)");
         }
@@ -343,6 +353,7 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
         if (he == hipSuccess) he = hipStreamSynchronize(nullptr);
         if (he != hipSuccess) {
             (void)hipFree(env->owned_logret);
+            if (env->ticket) (void)hipFree(env->ticket);
             delete env;
             return hip_fail(he, "fe_env_create: log-return table");
         }
@@ -363,9 +374,11 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
     p.A = A;
     if (int rc = configure_launch(env)) {
         if (env->owned_logret) (void)hipFree(env->owned_logret);
+        if (env->ticket) (void)hipFree(env->ticket);
         delete env;
         return rc;
     }
+    p.ticket = env->ticket;
     p.P = prices;
     p.LR = logret;
     p.N = cfg->N; p.D = cfg->D; p.L = cfg->L;
@@ -454,8 +467,8 @@ int fe_env_step_traj_notify(fe_env *env, const float *actions, void *obs, double
         return fail(FE_ERR_ARG, "fe_env_step_traj_notify: obs_src_out and obs_pos_out go together");
     if (actions_store_out == actions) actions_store_out = nullptr;
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step_notify: state not bound");
-    if (env->p.eval_env < 0)
-        return fail(FE_ERR_ARG, "fe_env_step_notify: this env has no evaluation env (evaluate mode, or a shard without it)");
+    if (env->p.eval_env < 0 && !env->cfg.evaluate)
+        return fail(FE_ERR_ARG, "fe_env_step_notify: this training-mode env has no evaluation env (a shard that does not own it)");
     return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream, obs_src_out, obs_pos_out, actions_store_out,
                              host_flag, seq);
 }
@@ -907,9 +920,10 @@ int fe_env_set_launch(fe_env *env, int32_t tile_envs, int32_t grid, int32_t roll
 const char *fe_build_tag(void) { return FE_BUILD_TAG; }
 
 int fe_env_destroy(fe_env *env) {
-    if (env && env->owned_logret) {
+    if (env && (env->owned_logret || env->ticket)) {
         DeviceGuard guard(env->device);
-        (void)hipFree(env->owned_logret);
+        if (env->owned_logret) (void)hipFree(env->owned_logret);
+        if (env->ticket) (void)hipFree(env->ticket);
     }
     delete env;
     return FE_OK;

@@ -466,6 +466,24 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
                 single_tile<OT, VEC, false, FORM>(p, l, stage, ps, tile, k, EB, e, lane, wave, PreTuples<OT>{});
         }
     }
+    // Evaluate mode has no evaluation env; what its host reads every step is "have ALL envs terminated?" (TSE:531), a
+    // fact of the whole launch.  In the notify form the LAST workgroup to finish reports the terminated-count:
+    // (seq << 32) | count into the host flag -- the host polls that instead of copying the counter back.
+    if constexpr (!RESET_ONLY && FORM == kFullNotify) {
+        if (p.evaluate) {
+            __threadfence();   // this thread's counter atomics are visible device-wide ...
+            __syncthreads();   // ... and so are those of the whole workgroup
+            if (tid == 0) {
+                const unsigned done = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                if (done == gridDim.x - 1) {
+                    __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                    const unsigned long long cnt = __hip_atomic_load(&p.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(p.host_flag, (p.flag_seq << 32) | (cnt & 0xffffffffull), __ATOMIC_RELAXED,
+                                       __HIP_MEMORY_SCOPE_SYSTEM);
+                }
+            }
+        }
+    }
 }
 
 }  // namespace

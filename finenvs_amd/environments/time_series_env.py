@@ -272,7 +272,9 @@ class TimeSeriesEnv:
         # device-to-host copy after the launch
         self._flag = None
         self._flag_seq = 0
-        if self.redraw == "torch" and self._eval_env >= 0:
+        if (self.redraw == "torch" and self._eval_env >= 0) or self.evaluate:
+            # (evaluate mode: the per-step host read is "have all envs terminated?", TSE:531 -- the notify form's last
+            # workgroup reports the count)
             flag = C.c_void_p()
             _lib.check(self._lib.fe_host_flag_create(C.byref(flag)))
             self._flag = flag
@@ -515,9 +517,10 @@ class TimeSeriesEnv:
             dones = dones_out
             if dones.dtype is not torch.int32 or dones.numel() != N or not dones.is_contiguous() or dones.device != self._dev:
                 raise ValueError("dones_out must be a contiguous int32 tensor of num_envs elements on the env's device")
-        notify = self._flag is not None
+        # (a hipGraph capture of evaluate-mode steps defers the host read to the end of the replay: plain launches there)
+        notify = self._flag is not None and not (self.evaluate and getattr(self, "_defer_evaluation_check", False))
         if notify:
-            self._flag_seq = seq = (self._flag_seq + 1) & 0x3FFFFFFFFFFFFFFF
+            self._flag_seq = seq = (self._flag_seq + 1) & (0x7FFFFFFF if self.evaluate else 0x3FFFFFFFFFFFFFFF)
         if descriptors_out is None and actions_out is None:
             if notify:
                 rc = self._lib.fe_env_step_notify(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
@@ -552,7 +555,7 @@ class TimeSeriesEnv:
         if self.evaluate and not getattr(self, "_defer_evaluation_check", False):
             # (GraphedRollout defers this host read to the end of a K-step replay: the per-env bookkeeping already ran in
             # the kernel, and steps past an env's termination cannot change its return, TSE:526-528)
-            info = self.record_evaluation_metrics()
+            info = self.record_evaluation_metrics(self._terminated_count(seq) if notify else None)
         elif self.redraw == "torch" and self._eval_env >= 0:
             # TSE:504-513: the eval env redraws a day from torch's global generator when it finishes
             if self._eval_env_done(seq) if notify else bool(dones[self._eval_env].item()):
@@ -560,10 +563,31 @@ class TimeSeriesEnv:
                 self.env_indices[self._eval_env : self._eval_env + 1] = torch.randint(0, D, (1,), device=self._dev)
         return (obs, rewards, dones, info)
 
-    def record_evaluation_metrics(self) -> Dict:
+    def _terminated_count(self, seq: int) -> int:
+        """Evaluate mode: poll the host flag until the launch with this sequence number has finished -- its last
+        workgroup stores (seq << 32) | terminated-count there -- instead of copying the counter back (TSE:531)."""
+        import time
+
+        word = self._flag_word
+        v = word.value
+        if (v >> 32) != seq:
+            t0 = time.monotonic()
+            spins = 0
+            while True:
+                v = word.value
+                if (v >> 32) == seq:
+                    break
+                spins += 1
+                if spins & 0xFFF == 0 and time.monotonic() - t0 > 60.0:
+                    torch.cuda.synchronize(self._dev)
+                    raise RuntimeError("the step kernel never reported its terminated-count")
+        return int(v & 0xFFFFFFFF)
+
+    def record_evaluation_metrics(self, terminated: Optional[int] = None) -> Dict:
         """TSE:523-536.  The per-env part ran inside the step kernel; this is the
-        torch.all(terminated) test and the hand-over of the returns."""
-        if int(self._counters[0].item()) == self.num_envs:
+        torch.all(terminated) test and the hand-over of the returns.  ``terminated``: the count if the caller already
+        has it (step() reads it from the host flag); else one device-to-host read."""
+        if (int(self._counters[0].item()) if terminated is None else terminated) == self.num_envs:
             info = {"returns": self.episode_returns.clone()}
             self.reset_evaluation_metrics()
             return info

@@ -126,9 +126,12 @@ int fe_env_step(fe_env *env, const float *actions, void *obs, double *rewards, i
  * evaluation env (cfg.eval_env) FIRST and stores (seq << 1) | done into *host_flag -- host memory from
  * fe_host_flag_create, system scope -- a few microseconds after the launch starts; the host polls the flag until it
  * carries `seq` (any value that changes per call) and can issue the next launches while this one is still streaming.
- * Tile order is the only difference to fe_env_step: results are identical.  FE_ERR_ARG if the env has no evaluation env
- * (evaluate mode, or a shard that does not own it).  fe_env_step_traj_notify is the same with fe_env_step_traj's optional
+ * Tile order is the only difference to fe_env_step: results are identical.  FE_ERR_ARG for a training-mode env without an
+ * evaluation env (a shard that does not own it).  fe_env_step_traj_notify is the same with fe_env_step_traj's optional
  * trajectory outputs (each may be NULL); bound episode statistics are updated by both.
+ * EVALUATE-mode envs have no evaluation env; their per-step host read is `torch.all(self.terminated_episodes)` (TSE:531),
+ * a fact of the whole launch: there the LAST workgroup to finish stores (seq << 32) | counters[0] (how many envs have
+ * terminated so far; seq < 2^31) into *host_flag, and the host compares the count with N.
  */
 int fe_env_step_notify(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
                        uint64_t *host_flag, uint64_t seq, void *stream);

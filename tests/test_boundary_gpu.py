@@ -324,10 +324,26 @@ def test_step_notify_equals_step_and_reports_the_eval_env_early(fe, fo, N, A, W,
         for x, y in ((a_env.cash, b_env.cash), (a_env.margin, b_env.margin), (a_env._spot0, b_env._spot0), (a_env.env_indices, b_env.env_indices)):
             assert torch.equal(x, y)
     assert seen_done >= 1  # 30-bar days: the evaluation env finished at least once (and redrew its day identically)
-    # no evaluation env -> refused
-    ev = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, evaluate=True, obs_dtype=dt)
-    rc = lib.fe_env_step_notify(ev._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), flag, 1, st)
+    # a training-mode shard without the evaluation env -> refused
+    sh = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=2 * N, rank=0, world_size=2, redraw="device", obs_dtype=dt)
+    rc = lib.fe_env_step_notify(sh._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), flag, 1, st)
     assert rc == _lib.FE_ERR_ARG and b"evaluation env" in lib.fe_last_error()
+    # evaluate mode: the LAST workgroup reports (seq << 32) | how many envs have terminated so far (TSE:531)
+    ev = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, evaluate=True, obs_dtype=dt)
+    ev2 = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, evaluate=True, obs_dtype=dt)
+    for k in range(1, 36):
+        a = (torch.rand((N, A), generator=g, device="cuda") * 2 - 1).float()
+        _lib.check(lib.fe_env_step_notify(ev._handle, a.data_ptr(), obs.data_ptr(), rew.data_ptr(), done.data_ptr(), flag, 70 + k, st))
+        torch.cuda.synchronize()
+        assert word.value >> 32 == 70 + k and (word.value & 0xFFFFFFFF) == int(ev._counters[0])
+        o2, r2, d2, info2 = ev2.step(a)  # the class's own evaluate-mode step (polls its own flag)
+        assert torch.equal(obs, o2) and torch.equal(rew, r2) and torch.equal(done, d2)
+        if "returns" in info2:  # all envs had terminated: the raw env's counter says the same, then clear it as step() did
+            assert int(ev._counters[0]) == N and torch.equal(ev.episode_returns, info2["returns"])
+            ev.reset_evaluation_metrics()
+            break
+    else:
+        raise AssertionError("no evaluation episode set finished within 35 steps of 30-bar days")
     # with trajectory outputs and bound episode statistics: the full form + flag, again equal to the plain calls
     from finenvs_amd.stats import EpisodeStats
 
