@@ -118,7 +118,20 @@ int main(int argc, char **argv) {
             const uint64_t seq = (uint64_t)s + 1;
             FECK(fe_env_step_notify(env, d_act, d_obs, d_rew, d_done, flag, seq, NULL));
             uint64_t v;
-            while (((v = *(volatile uint64_t *)flag) >> 1) != seq) { /* the launch is still running; only the flag is awaited */ }
+            /* the launch is still running; only the flag is awaited.  Bounded: every 2^16 polls ask the stream -- a launch that
+             * failed asynchronously, or finished without ever writing the flag, must end the wait with an error, not hang */
+            unsigned long spins = 0;
+            while (((v = *(volatile uint64_t *)flag) >> 1) != seq) {
+                if ((++spins & 0xFFFF) == 0) {
+                    hipError_t q = hipStreamQuery(NULL);
+                    if (q != hipErrorNotReady) {
+                        if (((v = *(volatile uint64_t *)flag) >> 1) == seq) break;
+                        fprintf(stderr, "step %d: the stream is %s but the host flag never carried seq %llu\n", s,
+                                q == hipSuccess ? "idle" : hipGetErrorString(q), (unsigned long long)seq);
+                        return 5;
+                    }
+                }
+            }
             eval_dones_flag += (long long)(v & 1);
         } else {
             FECK(fe_env_step(env, d_act, d_obs, d_rew, d_done, NULL));

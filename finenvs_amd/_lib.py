@@ -13,7 +13,7 @@ from typing import Optional
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libfinenvs_amd.so")
 
-FE_ABI_VERSION = 4
+FE_ABI_VERSION = 5
 FE_OK, FE_ERR_ARG, FE_ERR_HIP, FE_ERR_STATE = 0, -1, -2, -3
 FE_MAX_ASSETS = 256
 
@@ -32,7 +32,7 @@ class FeConfig(C.Structure):
     ]
 
 
-# name -> (restype, argtypes); every symbol the header declares
+# name -> (restype, argtypes); every symbol include/finenvs_amd.h (the frozen surface) declares
 _vp, _i64, _i32 = C.c_void_p, C.c_int64, C.c_int32
 SIGNATURES = {
     "fe_version": (C.c_int, []),
@@ -42,6 +42,7 @@ SIGNATURES = {
     "fe_env_bind_state": (C.c_int, [_vp] * 10),
     "fe_env_bind_f32_table": (C.c_int, [_vp, _vp]),
     "fe_env_bind_stats": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "fe_env_stats_reduce": (C.c_int, [_vp, _vp, _vp]),
     "fe_env_reset_obs": (C.c_int, [_vp, _vp, _vp]),
     "fe_env_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_env_describe": (C.c_int, [_vp, _vp, _vp, _vp]),
@@ -54,20 +55,9 @@ SIGNATURES = {
     "fe_env_check_descriptors": (C.c_int, [_vp, _vp, _i64, C.POINTER(_i64), _vp]),
     "fe_env_step_traj": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "fe_env_rollout_linear": (C.c_int, [_vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "fe_policy_table": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
-    "fe_env_rollout_table": (C.c_int, [_vp, _vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "fe_env_rollout_mlp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "fe_env_rollout_lstm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp,
-                                      _vp, _vp, _vp, _vp]),
-    "fe_lstm_activations": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
-    "fe_lstm_split_workspace_floats": (_i64, [_i32, _i64]),
-    "fe_env_rollout_lstm_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp,
-                                            _vp, _vp, _vp, _vp, _vp, _vp]),
-    "fe_lstm_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
     "fe_env_set_day": (C.c_int, [_vp, _i64, _i64, _vp]),
     "fe_env_launch_info": (C.c_int, [_vp, C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "fe_env_destroy": (C.c_int, [_vp]),
-    "fe_env_set_launch": (C.c_int, [_vp, _i32, _i32, _i32]),
     "fe_build_tag": (C.c_char_p, []),
     "fe_env_device": (C.c_int, [_vp]),
     "fe_env_logret": (_vp, [_vp]),
@@ -78,6 +68,20 @@ SIGNATURES = {
     "fe_traj_returns": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i64, C.c_double, _vp, _vp, _vp]),
     "fe_csv_count_lines": (_i64, [C.c_char_p]),
     "fe_csv_read": (_i64, [C.c_char_p, _i64, _i32, _vp, _vp, _vp, _vp]),
+}
+# include/finenvs_amd_ext.h: the experimental in-kernel policy heads and the tuning hook (same library)
+EXT_SIGNATURES = {
+    "fe_policy_table": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "fe_env_rollout_table": (C.c_int, [_vp, _vp, _vp, C.c_double, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fe_env_rollout_mlp": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fe_env_rollout_lstm": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp, _vp,
+                                      _vp, _vp, _vp, _vp]),
+    "fe_lstm_activations": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "fe_lstm_split_workspace_floats": (_i64, [_i32, _i64]),
+    "fe_env_rollout_lstm_split": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _vp, _vp, _vp, C.c_float, _vp, _vp,
+                                            _vp, _vp, _vp, _vp, _vp, _vp]),
+    "fe_lstm_forward": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _vp, _vp, _i64, _vp, _vp]),
+    "fe_env_set_launch": (C.c_int, [_vp, _i32, _i32, _i32]),
 }
 
 _lib: Optional[C.CDLL] = None
@@ -104,7 +108,7 @@ def load(path: Optional[str] = None) -> C.CDLL:
                 "finenvs_amd has no CPU fallback"
             ) from exc
     lib = C.CDLL(p)
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in {**SIGNATURES, **EXT_SIGNATURES}.items():
         fn = getattr(lib, name)  # AttributeError here means the .so is stale
         fn.restype = res
         fn.argtypes = args

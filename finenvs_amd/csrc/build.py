@@ -14,7 +14,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 REPO = os.path.dirname(os.path.dirname(HERE))
 SOURCES = ["fe_env.hip", "fe_csv.cpp"]
-HEADERS = ["fe_device_common.h", "fe_step_kernel.h", "fe_rollout_kernels.h", "fe_lstm_kernel.h", "fe_aux_kernels.h"]  # included by fe_env.hip
+HEADERS = ["fe_device_common.h", "fe_step_kernel.h", "fe_activations.h", "fe_rollout_kernels.h", "fe_lstm_kernel.h", "fe_aux_kernels.h"]  # included by fe_env.hip
 LIB = os.path.join(HERE, "libfinenvs_amd.so")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = [
@@ -28,7 +28,7 @@ def needs_build() -> bool:
     if not os.path.exists(LIB):
         return True
     t = os.path.getmtime(LIB)
-    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, h) for h in HEADERS] + [os.path.join(REPO, "include", "finenvs_amd.h")]
+    deps = [os.path.join(HERE, s) for s in SOURCES] + [os.path.join(HERE, h) for h in HEADERS] + [os.path.join(REPO, "include", h) for h in ("finenvs_amd.h", "finenvs_amd_ext.h")]
     return any(os.path.getmtime(d) > t for d in deps)
 
 

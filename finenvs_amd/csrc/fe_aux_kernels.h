@@ -118,6 +118,41 @@ __global__ __launch_bounds__(kBlock) void fe_tables_kernel(const double *__restr
     }
 }
 
+// ---- f4: fixed-order reduction of the per-env episode statistics (fe_env_stats_reduce) ----
+// acc is (N, 3) f64: per env the count, sum and sum of squares of its finished training episodes (the step kernels
+// add to env n's three slots, one writer per slot).  ONE workgroup of kStatsLanes lanes adds the envs up in an order
+// that is part of the contract (the test oracle restates it as fo_stats_reduce): per column k, lane t sums
+// x[t][k], x[t + 1024][k], ... in ascending order starting from +0.0, then a halving tree s[t] += s[t + stride],
+// stride = 512 ... 1.  Same bits whatever the step kernel's tile walk, launch geometry or form was.  Log-time only
+// (PPO_agent.py:146-163).
+constexpr int kStatsLanes = 1024;
+__global__ __launch_bounds__(kStatsLanes) void fe_stats_reduce_kernel(const double *__restrict__ acc, int64_t N,
+                                                                      double *__restrict__ out) {
+    __shared__ double sh[3][kStatsLanes];
+    const int t = threadIdx.x;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0;
+    int64_t j = t;
+    // two envs' triples in flight, added in index order
+    for (; j + (int64_t)kStatsLanes < N; j += 2 * (int64_t)kStatsLanes) {
+        const double *x = acc + 3 * j, *y = acc + 3 * (j + kStatsLanes);
+        const double a0 = x[0], a1 = x[1], a2 = x[2], b0 = y[0], b1 = y[1], b2 = y[2];
+        s0 += a0; s1 += a1; s2 += a2;
+        s0 += b0; s1 += b1; s2 += b2;
+    }
+    for (; j < N; j += kStatsLanes) {
+        const double *x = acc + 3 * j;
+        s0 += x[0]; s1 += x[1]; s2 += x[2];
+    }
+    sh[0][t] = s0; sh[1][t] = s1; sh[2][t] = s2;
+    __syncthreads();
+    for (int stride = kStatsLanes / 2; stride >= 1; stride >>= 1) {
+        if (t < stride)
+            for (int k = 0; k < 3; ++k) sh[k][t] += sh[k][t + stride];
+        __syncthreads();
+    }
+    if (t < 3) out[t] = sh[t][0];
+}
+
 // ---- f1: trajectory slot store ----
 __global__ __launch_bounds__(kBlock) void fe_traj_store_kernel(int64_t N, int64_t NA,
                                                                const float *__restrict__ actions,

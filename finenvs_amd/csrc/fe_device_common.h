@@ -93,7 +93,7 @@ struct Params {
     float *ep_ret;
     unsigned long long *counters;
     float *run_ret;      // optional episode statistics (fe_env_bind_stats): running return per env
-    double *stat_acc;    // [0] finished training episodes, [1] sum of their returns, [2] sum of squares
+    double *stat_acc;    // (N, 3) per-env partials: [3n] finished training episodes of env n, [3n + 1] sum of their returns, [3n + 2] sum of squares
     float *stat_eval;    // [0] return of the eval env's last finished episode, [1] how many it finished
     const float *actions;
     void *obs;

@@ -25,11 +25,12 @@
 // iterations with 4 (f64) / 6 (f32) workgroups per CU, and the first tile's table
 // loads are issued before its accounting.
 //
-// One translation unit, six files:
+// One translation unit, seven files:
 //   fe_device_common.h    constants / build knobs, Params, Philox, sleeve accounting, LDS tile layout, input loads
 //   fe_step_kernel.h      fe_env_kernel (the fused step and reset() rendering)
 //   fe_rollout_kernels.h  K-step fused rollouts with an in-kernel policy: linear window / table form, MLP head (MFMA)
-//   fe_lstm_kernel.h      K-step fused rollout with the reference's LSTM actor (MFMA), exact-operation sigmoid / tanh
+//   fe_activations.h      exact-operation sigmoid / tanh shared by the LSTM and MLP heads
+//   fe_lstm_kernel.h      K-step fused rollout with the reference's LSTM actor (MFMA)
 //   fe_aux_kernels.h      descriptor / render kernels, init kernels (log-returns, day tables), trajectory kernels
 //   fe_env.hip            (this file) launch geometry, the env object, the C ABI of include/finenvs_amd.h
 //
@@ -48,6 +49,7 @@
 #include <type_traits>
 
 #include "finenvs_amd.h"
+#include "finenvs_amd_ext.h"
 
 #include "fe_device_common.h"
 #include "fe_step_kernel.h"
@@ -439,6 +441,17 @@ int fe_env_bind_stats(fe_env *env, float *running_returns, double *accumulators,
     env->p.run_ret = running_returns;
     env->p.stat_acc = accumulators;
     env->p.stat_eval = eval_return;
+    return FE_OK;
+}
+
+int fe_env_stats_reduce(fe_env *env, double *out, void *stream) {
+    if (!env || !out) return fail(FE_ERR_ARG, "fe_env_stats_reduce: null argument");
+    if (!env->p.stat_acc) return fail(FE_ERR_STATE, "fe_env_stats_reduce: no statistics bound (fe_env_bind_stats)");
+    DeviceGuard guard(env->device);
+    if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
+    hipLaunchKernelGGL(fe_stats_reduce_kernel, dim3(1), dim3(kStatsLanes), 0, (hipStream_t)stream, env->p.stat_acc, env->p.N, out);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_env_stats_reduce launch");
     return FE_OK;
 }
 

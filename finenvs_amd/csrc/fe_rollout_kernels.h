@@ -2,6 +2,7 @@
 #pragma once
 #include "fe_device_common.h"
 #include "fe_step_kernel.h"
+#include "fe_activations.h"
 
 namespace {
 
@@ -100,9 +101,10 @@ __device__ __forceinline__ void account_keep(const Params &p, const TileLds &l, 
                     p.stat_eval[0] = cr;
                     p.stat_eval[1] += 1.0f;
                 } else {
-                    atomicAdd(&p.stat_acc[0], 1.0);
-                    atomicAdd(&p.stat_acc[1], (double)cr);
-                    atomicAdd(&p.stat_acc[2], (double)cr * (double)cr);
+                    double *acc = p.stat_acc + 3 * n;  // per-env partial sums with one writer each, as in fe_step_kernel.h
+                    atomicAdd(acc, 1.0);
+                    atomicAdd(acc + 1, (double)cr);
+                    atomicAdd(acc + 2, (double)cr * (double)cr);
                 }
                 cr = 0.0f;
             }
@@ -421,7 +423,10 @@ __host__ __device__ inline size_t mlp_lds_bytes(int EB, int A, int W, int H) {
 template <int ACT>
 __device__ __forceinline__ float mlp_act(float z) {
     if constexpr (ACT == 1) return z > 0.0f ? z : (z != z ? z : 0.0f);
-    if constexpr (ACT == 2) return tanhf(z);
+    // tanh: the exact-operation form of the LSTM head (fe_activations.h) -- branch-free and bit-reproducible on the CPU.
+    // libm's tanhf, inlined 32 * NT times with its branches, left H = 128 no registers for the sleeve state (it went to
+    // scratch memory: 72 bytes per lane); absolute error <= 1.2e-7 either way.
+    if constexpr (ACT == 2) return lstm_tanh(z);
     // ELU, alpha = 1.  exp through v_exp_f32 (__expf), not expm1f: the second layer is VALU-bound (32 hidden units per
     // lane and block) and expm1f costs ~25 instructions per unit; the absolute error of exp(z) - 1 is <= 2e-7 per
     // unit (an ulp of 1.0), inside the 2e-6 tolerance of the action (tests/test_mlp_rollout_gpu.py)

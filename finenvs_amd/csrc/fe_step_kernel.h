@@ -109,9 +109,15 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
                         p.stat_eval[0] = cr;
                         p.stat_eval[1] += 1.0f;
                     } else {
-                        atomicAdd(&p.stat_acc[0], 1.0);
-                        atomicAdd(&p.stat_acc[1], (double)cr);
-                        atomicAdd(&p.stat_acc[2], (double)cr * (double)cr);
+                        // per-env partial sums: env n's slots have ONE writer (the lane that owns env n; launches are
+                        // stream-ordered), so what they add up to does not depend on the tile walk, the launch geometry
+                        // or the form of the kernel; fe_env_stats_reduce adds the envs up in a fixed order.  The adds
+                        // are issued as no-return memory atomics only so that the old values never occupy registers
+                        // (as plain read-modify-writes they cost the f32 notify form a VGPR spill).
+                        double *acc = p.stat_acc + 3 * n;  // (N, 3): one address, three immediate offsets
+                        atomicAdd(acc, 1.0);
+                        atomicAdd(acc + 1, (double)cr);
+                        atomicAdd(acc + 2, (double)cr * (double)cr);
                     }
                     cr = 0.0f;
                 }

@@ -36,6 +36,46 @@ from ..spaces import Box
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+class HostFlagTimeout(RuntimeError):
+    """The step kernel never reported through its host flag (see ``poll_host_word``)."""
+
+
+def poll_host_word(read, matches, timeout_s: float, on_timeout=None, spin: int = 2000, clock=None, sleep=None) -> int:
+    """Wait until ``matches(read())`` and return that word: the host half of fe_env_step_notify (the reference's
+    per-step host read, TSE:510 / TSE:531, without its device-to-host copy).  The kernel writes the word a few
+    microseconds after it starts, so the first ``spin`` polls are a tight loop; after that the thread yields
+    (``sleep(0)``), and from 20 ms on it sleeps 50 us per poll -- a stream that is merely slow (queued work ahead, a
+    profiler, a shared GPU) does not cost a core.  After ``timeout_s``: ``on_timeout()`` (the caller synchronises its
+    stream there, which surfaces a launch / kernel error and lets a slow launch finish), then ONE more read -- only if
+    the word still does not match is ``HostFlagTimeout`` raised."""
+    import time
+
+    clock = clock or time.monotonic
+    sleep = sleep or time.sleep
+    v = read()
+    if matches(v):
+        return v
+    for _ in range(spin):
+        v = read()
+        if matches(v):
+            return v
+    t0 = clock()
+    while True:
+        v = read()
+        if matches(v):
+            return v
+        el = clock() - t0
+        if el > timeout_s:
+            if on_timeout is not None:
+                on_timeout()
+            v = read()
+            if matches(v):
+                return v
+            raise HostFlagTimeout(f"the step kernel did not report through its host flag within {timeout_s:g} s "
+                                  f"(last word {v:#x})")
+        sleep(0.0 if el < 0.02 else 50e-6)
+
+
 def shard_range(num_envs: int, rank: int, world_size: int) -> Tuple[int, int]:
     """Contiguous block of envs owned by ``rank``."""
     base, rem = divmod(num_envs, world_size)
@@ -272,6 +312,7 @@ class TimeSeriesEnv:
         # device-to-host copy after the launch
         self._flag = None
         self._flag_seq = 0
+        self.flag_timeout_s = 60.0  # how long step() waits for the kernel's word before it synchronises and gives up
         if (self.redraw == "torch" and self._eval_env >= 0) or self.evaluate:
             # (evaluate mode: the per-step host read is "have all envs terminated?", TSE:531 -- the notify form's last
             # workgroup reports the count)
@@ -360,25 +401,20 @@ class TimeSeriesEnv:
             self._lib.fe_env_destroy(h)
             self._handle = None
 
+    def _poll_flag(self, shift: int, seq: int) -> int:
+        """The host flag's word once its sequence field (bits ``shift`` and up) carries ``seq``."""
+        word = self._flag_word
+        for _ in range(2000):  # the usual case, inline: the word arrives 8 - 11 us after the launch call
+            v = word.value
+            if (v >> shift) == seq:
+                return v
+        return poll_host_word(lambda: word.value, lambda v: (v >> shift) == seq, self.flag_timeout_s,
+                              on_timeout=lambda: torch.cuda.synchronize(self._dev), spin=0)
+
     def _eval_env_done(self, seq: int) -> bool:
         """Poll the host flag of fe_env_step_notify until it carries this step's sequence number; its low bit is the
         evaluation env's done flag (TSE:510).  The kernel writes it a few microseconds after it starts."""
-        import time
-
-        word = self._flag_word
-        v = word.value
-        if (v >> 1) != seq:
-            t0 = time.monotonic()
-            spins = 0
-            while True:
-                v = word.value
-                if (v >> 1) == seq:
-                    break
-                spins += 1
-                if spins & 0xFFF == 0 and time.monotonic() - t0 > 60.0:
-                    torch.cuda.synchronize(self._dev)  # surfaces a launch / kernel error if there was one
-                    raise RuntimeError("the step kernel never reported the evaluation env's done flag")
-        return bool(v & 1)
+        return bool(self._poll_flag(1, seq) & 1)
 
     # ------------------------------------------------------------------ reference-compatible views
     @property
@@ -519,6 +555,13 @@ class TimeSeriesEnv:
                 raise ValueError("dones_out must be a contiguous int32 tensor of num_envs elements on the env's device")
         # (a hipGraph capture of evaluate-mode steps defers the host read to the end of the replay: plain launches there)
         notify = self._flag is not None and not (self.evaluate and getattr(self, "_defer_evaluation_check", False))
+        if notify and torch.cuda.is_current_stream_capturing():
+            # a captured launch does not run: the host flag would be polled for a kernel that is not executing (and the
+            # reference's own `.item()` read fails under capture just the same)
+            raise RuntimeError("TimeSeriesEnv.step() in its default mode reads a per-step host flag (the reference's "
+                               "dones[-1].item(), TSE:510; evaluate mode: TSE:531) and cannot be captured into a "
+                               "hipGraph: construct the env with redraw='device', or capture through "
+                               "finenvs_amd.rollout.GraphedRollout (which defers the evaluate-mode read)")
         if notify:
             self._flag_seq = seq = (self._flag_seq + 1) & (0x7FFFFFFF if self.evaluate else 0x3FFFFFFFFFFFFFFF)
         if descriptors_out is None and actions_out is None:
@@ -566,22 +609,7 @@ class TimeSeriesEnv:
     def _terminated_count(self, seq: int) -> int:
         """Evaluate mode: poll the host flag until the launch with this sequence number has finished -- its last
         workgroup stores (seq << 32) | terminated-count there -- instead of copying the counter back (TSE:531)."""
-        import time
-
-        word = self._flag_word
-        v = word.value
-        if (v >> 32) != seq:
-            t0 = time.monotonic()
-            spins = 0
-            while True:
-                v = word.value
-                if (v >> 32) == seq:
-                    break
-                spins += 1
-                if spins & 0xFFF == 0 and time.monotonic() - t0 > 60.0:
-                    torch.cuda.synchronize(self._dev)
-                    raise RuntimeError("the step kernel never reported its terminated-count")
-        return int(v & 0xFFFFFFFF)
+        return int(self._poll_flag(32, seq) & 0xFFFFFFFF)
 
     def record_evaluation_metrics(self, terminated: Optional[int] = None) -> Dict:
         """TSE:523-536.  The per-env part ran inside the step kernel; this is the

@@ -90,6 +90,10 @@ class GraphedRollout:
         """Replay the K captured steps; returns the newest observation (a static buffer).  In evaluate mode
         ``self.info`` then holds ``{"returns": ...}`` if every env has finished its episode by now (TSE:523-536), else {}."""
         self.graph.replay()
+        # the replay advanced the env K steps without passing through env.step(): fused rollout objects sharing this env
+        # must see their observation descriptors as stale (_FusedEvaluation._begin_run).  Callers that step through
+        # the C ABI directly bypass this guard.
+        self.env._generation += self.K
         if self.traj is not None:
             self.traj.t = self.K
         self.info = self.env.record_evaluation_metrics() if self.env.evaluate else {}

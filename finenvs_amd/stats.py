@@ -5,8 +5,13 @@ The reference's agents track, per rollout step and with a host sync each time
 returns of finished *training* episodes (all envs but the last), and the return of the last
 finished *evaluation* episode (the last env); at log time they report
 ``len(list), mean(list), std(list)``.  ``EpisodeStats`` binds three small device buffers to
-the env; the fused step kernel updates them (atomics for the finished-episode sums) and
-``read()`` fetches the numbers with a single device-to-host copy at log time.
+the env; the fused step kernel updates them -- the finished-episode sums as PER-ENV partials
+(N, 3) f64, each slot written only by the lane that owns the env -- and ``read()`` adds the
+partials up in a fixed order (``fe_env_stats_reduce``: one workgroup, lane-strided sums and a
+halving tree; the test oracle restates it) and fetches the numbers with a single
+device-to-host copy at log time.  Mean / std are therefore bit-stable from run to run and do
+not depend on the kernel's tile walk, launch geometry or form (the reference reduces its list
+in a fixed order too, PPO_agent.py:146-163).
 """
 from __future__ import annotations
 
@@ -25,7 +30,8 @@ class EpisodeStats:
         self.env = env
         dev = env._dev
         self.running_returns = torch.zeros((env.num_envs,), dtype=torch.float32, device=dev)
-        self._acc = torch.zeros((3,), dtype=torch.float64, device=dev)
+        self._acc = torch.zeros((env.num_envs, 3), dtype=torch.float64, device=dev)  # per-env partial sums
+        self._sums = torch.zeros((3,), dtype=torch.float64, device=dev)
         self._eval = torch.zeros((2,), dtype=torch.float32, device=dev)
         _lib.check(env._lib.fe_env_bind_stats(env._handle, self.running_returns.data_ptr(), self._acc.data_ptr(),
                                               self._eval.data_ptr()))
@@ -35,7 +41,8 @@ class EpisodeStats:
 
     def read(self, reset: bool = True) -> Dict[str, float]:
         """One D2H copy: what PPOAgent.log_progress prints (PPO_agent.py:146-163)."""
-        acc = self._acc.cpu()
+        _lib.check(self.env._lib.fe_env_stats_reduce(self.env._handle, self._sums.data_ptr(), self.env._stream()))
+        acc = self._sums.cpu()
         ev = self._eval.cpu()
         n, s, ss = float(acc[0]), float(acc[1]), float(acc[2])
         mean = s / n if n > 0 else float("nan")

@@ -409,6 +409,8 @@ void fo_f32_iadd_f64(const float *base, const double *delta, int64_t n, int32_t 
  */
 void fo_episode_stats_step(int64_t N, int64_t eval_env, const double *rew, const int32_t *done, float *running,
                            double *acc, float *eval) {
+    /* acc is (N, 3): PER-ENV partial sums (count, sum, sum of squares of env n's finished training episodes) --
+     * the layout fe_env_bind_stats documents; fo_stats_reduce adds the envs up in the build's fixed order. */
     for (int64_t n = 0; n < N; ++n) {
         float cr = (float)((double)running[n] + rew[n]);  /* PPO_agent.py:121 */
         if (done[n]) {
@@ -416,13 +418,34 @@ void fo_episode_stats_step(int64_t N, int64_t eval_env, const double *rew, const
                 eval[0] = cr;
                 eval[1] += 1.0f;
             } else {                                       /* PPO_agent.py:122-128, 132 */
-                acc[0] += 1.0;
-                acc[1] += (double)cr;
-                acc[2] += (double)cr * (double)cr;
+                acc[3 * n] += 1.0;
+                acc[3 * n + 1] += (double)cr;
+                acc[3 * n + 2] += (double)cr * (double)cr;
             }
             cr = 0.0f;
         }
         running[n] = cr;
+    }
+}
+
+/*
+ * The summation order of fe_env_stats_reduce (include/finenvs_amd.h), which turns the per-env partials into what
+ * log_progress reports (len / mean / std of the finished-return list, PPO_agent.py:146-163): per column k of the
+ * (N, 3) array, 1024 lanes, lane t adds envs t, t + 1024, ... in ascending order starting from +0.0, then a halving
+ * tree s[t] += s[t + stride], stride = 512 ... 1.  out[k] = the reduced column k.
+ */
+void fo_stats_reduce(const double *acc, int64_t N, double *out) {
+    enum { LANES = 1024 };
+    double s[LANES];
+    for (int k = 0; k < 3; ++k) {
+        for (int t = 0; t < LANES; ++t) {
+            double v = 0.0;
+            for (int64_t j = t; j < N; j += LANES) v += acc[3 * j + k];
+            s[t] = v;
+        }
+        for (int stride = LANES / 2; stride >= 1; stride >>= 1)
+            for (int t = 0; t < stride; ++t) s[t] += s[t + stride];
+        out[k] = s[0];
     }
 }
 
@@ -529,11 +552,12 @@ void fo_policy_table_actions(const double *table, double wsum, double bias, cons
  *             chain of the HIP kernel;
  *   action  = clamp(b2 + (P0 + P1), -1, 1), P_half = fmaf chain over the hidden units
  *             32t + (r&3) + 8(r>>2) + 4*half, t and r ascending, of w2[h] * act(pre[h]).
- * act: 0 ELU (alpha 1, expm1f), 1 ReLU (NaN passes), 2 tanh.  w1t is (H, 4W): w1t[h][4j+c] = W1[5j+c][h].
+ * act: 0 ELU (alpha 1, expm1f), 1 ReLU (NaN passes), 2 tanh (the build's exact-operation form, fo_lstm_tanh).  w1t is (H, 4W): w1t[h][4j+c] = W1[5j+c][h].
  */
+float fo_lstm_tanh(float x);  /* the exact-operation tanh of the build's heads, below */
 static float fo_mlp_act(float z, int act) {
     if (act == 1) return z > 0.0f ? z : (z != z ? z : 0.0f);
-    if (act == 2) return tanhf(z);
+    if (act == 2) return fo_lstm_tanh(z);  /* bit-reproducible (ELU is not: the kernel's v_exp_f32 vs expm1f) */
     return z > 0.0f ? z : expm1f(z);
 }
 

@@ -111,12 +111,13 @@ def f32_iadd_f64(base: np.ndarray, delta: np.ndarray, subtract: bool = False) ->
 
 
 class EpisodeStatsOracle:
-    """PPO_agent.py:120-132 / 146-163 on numpy state (count / sum / sum of squares instead of a list)."""
+    """PPO_agent.py:120-132 / 146-163 on numpy state (per-env count / sum / sum of squares instead of a list, added up
+    in the fixed order of fe_env_stats_reduce: the build's contract, restated by fo_stats_reduce)."""
 
     def __init__(self, num_envs: int, eval_env: int):
         self.N, self.eval_env = int(num_envs), int(eval_env)
         self.running = np.zeros(self.N, dtype=np.float32)
-        self.acc = np.zeros(3, dtype=np.float64)
+        self.acc = np.zeros((self.N, 3), dtype=np.float64)
         self.eval = np.zeros(2, dtype=np.float32)
 
     def step(self, rewards: np.ndarray, dones: np.ndarray) -> None:
@@ -126,7 +127,9 @@ class EpisodeStatsOracle:
                                     _p(self.running), _p(self.acc), _p(self.eval))
 
     def read(self, reset: bool = True):
-        n, s, ss = (float(x) for x in self.acc)
+        sums = np.zeros(3, dtype=np.float64)
+        lib().fo_stats_reduce(_p(self.acc), C.c_int64(self.N), _p(sums))
+        n, s, ss = (float(x) for x in sums)
         mean = s / n if n > 0 else float("nan")
         var = (ss - n * mean * mean) / (n - 1) if n > 1 else float("nan")
         out = {"num_training_episodes": int(n), "mean_training_return": mean,

@@ -365,9 +365,10 @@ def test_step_notify_equals_step_and_reports_the_eval_env_early(fe, fo, N, A, W,
     ra, rb = sa.read(), sb.read()
     assert ra["num_training_episodes"] == rb["num_training_episodes"] > 0
     assert ra["evaluation_return"] == rb["evaluation_return"] and ra["num_evaluation_episodes"] == rb["num_evaluation_episodes"]
-    # the finished-episode sums are atomics: the reversed tile walk adds them in another order (last-ulp differences)
-    assert ra["mean_training_return"] == pytest.approx(rb["mean_training_return"], rel=1e-12)
-    assert ra["std_dev_training_return"] == pytest.approx(rb["std_dev_training_return"], rel=1e-10)
+    # the finished-episode sums are per-env partials added up in a fixed order (fe_env_stats_reduce): the notify form's
+    # reversed tile walk gives the same bits
+    assert ra["mean_training_return"] == rb["mean_training_return"]
+    assert ra["std_dev_training_return"] == rb["std_dev_training_return"]
     sa.close()
     sb.close()
     torch.cuda.synchronize()
@@ -402,6 +403,61 @@ def test_default_mode_polls_the_host_flag_and_keeps_the_reference_rng_stream(fe,
     assert runs[0][0] == runs[1][0] and len(set(runs[0][0])) > 1
     assert runs[0][1] == runs[1][1], "the global generator must be in the same state afterwards"
     assert torch.equal(runs[0][2], runs[1][2])
+
+
+def test_default_mode_step_refuses_stream_capture_at_once(fe, fo):
+    """The class-default step() reads a host flag every step (TSE:510; evaluate mode TSE:531).  Under a caller's own
+    stream capture the launch does not run, so the flag would be polled for a kernel that is not executing: step()
+    must raise immediately (the reference's `.item()` fails under capture just the same), not spin for its timeout and
+    then synchronise mid-capture.  redraw="device" captures fine."""
+    import time
+
+    from finenvs_amd.data import synthetic
+
+    prices, day_id, _ = synthetic.synthetic_series(7, 1, 24, 8)
+    for kw in ({}, {"evaluate": True}):
+        env = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=4, num_envs=9, obs_buffers=1, **kw)
+        assert env._flag is not None
+        a = torch.zeros((9, 1), device=env.device)
+        env.step(a)  # allocator / lazy init outside the capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        t0 = time.monotonic()
+        with pytest.raises(RuntimeError, match="cannot be captured"):
+            with torch.cuda.graph(g):
+                env.step(a)
+        assert time.monotonic() - t0 < 5.0
+        env.step(a)  # the env is still usable afterwards (nothing was launched, the sequence number did not move)
+        torch.cuda.synchronize()
+    env = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=4, num_envs=9, obs_buffers=1, redraw="device")
+    a = torch.zeros((9, 1), device=env.device)
+    rew, done = torch.empty((9,), dtype=torch.float64, device=env.device), torch.empty((9,), dtype=torch.int32, device=env.device)
+    env.step(a, rewards_out=rew, dones_out=done)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        env.step(a, rewards_out=rew, dones_out=done)
+    before = env._spot0.clone()
+    g.replay()
+    torch.cuda.synchronize()
+    assert not torch.equal(before, env._spot0)
+
+
+def test_host_flag_wait_synchronises_once_and_rereads_before_it_gives_up(fe, fo):
+    """A word that never arrives (here: the flag is polled for a sequence number no launch carries) ends in
+    HostFlagTimeout after `flag_timeout_s`, having synchronised the stream; the env keeps working afterwards."""
+    from finenvs_amd.data import synthetic
+    from finenvs_amd.environments.time_series_env import HostFlagTimeout
+
+    prices, day_id, _ = synthetic.synthetic_series(7, 1, 24, 8)
+    env = fe.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=4, num_envs=9)
+    a = torch.zeros((9, 1), device=env.device)
+    env.step(a)
+    env.flag_timeout_s = 0.2
+    with pytest.raises(HostFlagTimeout, match="host flag"):
+        env._eval_env_done(env._flag_seq + 12345)
+    env.step(a)
+    torch.cuda.synchronize()
 
 
 def test_env_objects_can_be_driven_from_different_host_threads(fe, fo):

@@ -26,10 +26,10 @@ def test_plain_c_host_matches_python_binding(tmp_path):
                            "-L", f"{rocm}/lib", "-lamdhip64", f"-Wl,-rpath,{libdir}", f"-Wl,-rpath,{rocm}/lib", "-lm",
                            "-o", exe])
     N, W, steps = 3000, 16, 120
-    out = subprocess.check_output([exe, str(N), str(W), str(steps)], text=True)
+    out = subprocess.check_output([exe, str(N), str(W), str(steps)], text=True, timeout=120)
     got = {k: float(v) for k, v in re.findall(r"(\w+)=([-+0-9.eE]+)", out.splitlines()[-1])}
     # the same run through fe_env_step_notify (host flag polled from C instead of reading dones[-1]): identical output
-    out_notify = subprocess.check_output([exe, str(N), str(W), str(steps), "notify"], text=True)
+    out_notify = subprocess.check_output([exe, str(N), str(W), str(steps), "notify"], text=True, timeout=120)
     assert out_notify.splitlines()[-1] == out.splitlines()[-1]
     assert got["eval_dones"] >= 1
 

@@ -9,7 +9,8 @@ import pytest
 import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HEADER = os.path.join(REPO, "include", "finenvs_amd.h")
+HEADER = os.path.join(REPO, "include", "finenvs_amd.h")          # the frozen surface
+EXT_HEADER = os.path.join(REPO, "include", "finenvs_amd_ext.h")  # experimental policy heads + tuning hook
 
 
 @pytest.fixture(scope="module")
@@ -19,8 +20,11 @@ def lib():
     return _lib.load()
 
 
-def declared_symbols():
-    text = open(HEADER).read()
+def declared_symbols(header=None):
+    """Function names a header declares (both headers when none is named)."""
+    if header is None:
+        return sorted(set(declared_symbols(HEADER)) | set(declared_symbols(EXT_HEADER)))
+    text = open(header).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(fe_[a-z0-9_]+)\s*\(", text)))
 
@@ -28,12 +32,28 @@ def declared_symbols():
 def test_header_symbols_are_all_exported_and_bound(lib):
     from finenvs_amd import _lib
 
-    names = declared_symbols()
-    assert len(names) >= 14
-    for n in names:
-        assert hasattr(lib, n), f"{n} declared in the header but not exported"
-        assert n in _lib.SIGNATURES, f"{n} has no ctypes signature"
-    assert sorted(_lib.SIGNATURES) == names
+    for header, table in ((HEADER, _lib.SIGNATURES), (EXT_HEADER, _lib.EXT_SIGNATURES)):
+        names = declared_symbols(header)
+        assert len(names) >= 9
+        for n in names:
+            assert hasattr(lib, n), f"{n} declared in {os.path.basename(header)} but not exported"
+            assert n in table, f"{n} has no ctypes signature"
+        assert sorted(table) == names
+    assert not set(_lib.SIGNATURES) & set(_lib.EXT_SIGNATURES)
+
+
+def test_the_frozen_header_stays_frozen():
+    """include/finenvs_amd.h is SURVEY 8(b)'s list + the 8(f) rows; the policy heads and the tuning hook are confined to
+    the experimental header, which takes no new exports (task 7)."""
+    core, ext = set(declared_symbols(HEADER)), set(declared_symbols(EXT_HEADER))
+    for n in ("fe_version", "fe_env_create", "fe_env_bind_state", "fe_env_reset_obs", "fe_env_step", "fe_env_set_day",
+              "fe_env_destroy", "fe_build_logret"):  # SURVEY 8(b) (fe_cpu_step deliberately absent: no CPU path in the product)
+        assert n in core
+    assert not any("lstm" in n or "mlp" in n or "policy" in n or n == "fe_env_set_launch" for n in core)
+    assert ext == {"fe_policy_table", "fe_env_rollout_table", "fe_env_rollout_mlp", "fe_env_rollout_lstm",
+                   "fe_lstm_split_workspace_floats", "fe_env_rollout_lstm_split", "fe_lstm_forward", "fe_lstm_activations",
+                   "fe_env_set_launch"}
+    assert len(core) == 33
 
 
 def test_version_and_struct_layout(lib, tmp_path):
@@ -102,7 +122,7 @@ def test_integration_doc_names_every_entry_point():
 
 
 def test_header_cites_reference_lines_for_every_compute_entry_point():
-    text = open(HEADER).read()
+    text = open(HEADER).read() + open(EXT_HEADER).read()
     blocks = re.findall(r"/\*(.*?)\*/\s*((?:int|int64_t|const char \*)\s*\*?fe_[a-z0-9_]+\s*\([^;]*;(?:\s*(?:int|int64_t)\s+fe_[a-z0-9_]+\s*\([^;]*;)*)", text, flags=re.S)
     cited = {}
     for comment, decls in blocks:

@@ -249,3 +249,51 @@ def test_lstm_weight_packing_host_side_matches_the_oracle_packing():
         NG = H // 8
         for mt, g, lane, c in ((0, 0, 0, 0), (1, 2, 37, 3), (4 * H // 32 - 1, NG - 1, 63, 1), (3, 1, 31, 2)):
             assert frag[((mt * NG + g) * 64 + lane) * 4 + c] == whh[32 * mt + (lane & 31), 8 * g + 4 * (lane >> 5) + c]
+
+
+def test_host_flag_poll_backs_off_and_rereads_after_the_timeout_synchronise():
+    """poll_host_word (the host half of fe_env_step_notify; replaces the reference's per-step dones[-1].item(), TSE:510):
+    a word that arrives late is returned, not reported as an error -- even when it only arrives while the timeout
+    handler synchronises the stream --, a word that never arrives raises HostFlagTimeout after ONE
+    call of the handler, and past the tight-spin phase the poll yields the CPU instead of burning it."""
+    from finenvs_amd.environments.time_series_env import HostFlagTimeout, poll_host_word
+
+    class Clock:  # a fake monotonic clock advanced by the fake sleep: no real waiting in the test
+        def __init__(self):
+            self.t, self.sleeps = 0.0, []
+
+        def now(self):
+            return self.t
+
+        def sleep(self, dt):
+            self.sleeps.append(dt)
+            self.t += max(dt, 1e-3)
+
+    seq = 7
+    # 1. already there: no polling at all
+    reads = []
+    assert poll_host_word(lambda: reads.append(1) or (seq << 1 | 1), lambda v: v >> 1 == seq, 1.0) == (seq << 1 | 1)
+    assert len(reads) == 1
+    # 2. arrives during the back-off phase
+    c, n = Clock(), [0]
+
+    def late():
+        n[0] += 1
+        return (seq << 1) if n[0] > 50 else ((seq - 1) << 1 | 1)
+
+    assert poll_host_word(late, lambda v: v >> 1 == seq, 10.0, spin=10, clock=c.now, sleep=c.sleep) == seq << 1
+    assert c.sleeps and c.sleeps[0] == 0.0 and c.sleeps[-1] == 50e-6  # yields first, sleeps from 20 ms on
+    # 3. arrives only because the timeout handler drained the stream: returned, no error
+    c, word, calls = Clock(), [0], []
+
+    def drain():
+        calls.append(1)
+        word[0] = seq << 1 | 1
+
+    assert poll_host_word(lambda: word[0], lambda v: v >> 1 == seq, 0.5, on_timeout=drain, spin=3, clock=c.now, sleep=c.sleep) & 1
+    assert calls == [1]
+    # 4. never arrives: one handler call, then the error (with the last word in the text)
+    c, calls = Clock(), []
+    with pytest.raises(HostFlagTimeout, match="0x4"):
+        poll_host_word(lambda: 4, lambda v: v >> 1 == seq, 0.5, on_timeout=lambda: calls.append(1), spin=3, clock=c.now, sleep=c.sleep)
+    assert calls == [1]

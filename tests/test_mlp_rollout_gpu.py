@@ -3,9 +3,10 @@
 * ReLU: the whole K-step rollout -- actions, rewards, dones, state -- equals the oracle's loop
   ``actions = fo.policy_mlp(obs); obs, r, d = step(actions)`` BIT FOR BIT: the v_mfma_f32_32x32x2_f32 accumulation is
   an fmaf chain whose order oracle/fe_oracle.c:fo_policy_mlp restates.
-* ELU (the reference's default activation) / tanh: device expm1f / tanhf differ from libm's by an ulp or two, so the
+* ELU (the reference's default activation): the device's v_exp_f32 differs from libm's expm1f by an ulp or two, so the
   actions are compared with a tolerance of 2e-6 absolute (actions live in [-1, 1]); the env is kept in lock-step by
   feeding the DEVICE's actions to the oracle, and everything downstream of the actions stays bit-exact.
+* tanh: the exact-operation form shared with the LSTM head -- bit for bit, like ReLU.
 * against a plain fp32 PyTorch ``nn.Sequential(Flatten, Linear, ELU, Linear)`` on the rendered observation: 1e-5
   absolute (a different summation order: that is the tolerance north_star states for floating point).
 """
@@ -111,11 +112,13 @@ def test_mlp_rollout_relu_equals_oracle_loop_bit_for_bit(fe, fo, N, A, W, H, day
     assert len(seen) >= 5, "the policy must actually trade in both directions"
 
 
-@pytest.mark.parametrize("activation,act", [("elu", 0), ("tanh", 2)])
-def test_mlp_rollout_elu_tanh_within_tolerance_in_lockstep(fe, fo, activation, act):
+@pytest.mark.parametrize("activation,act,H,atol", [("elu", 0, 64, 2e-6), ("tanh", 2, 64, 0.0), ("tanh", 2, 128, 0.0)])
+def test_mlp_rollout_elu_tanh_within_tolerance_in_lockstep(fe, fo, activation, act, H, atol):
+    """ELU: tolerance 2e-6 absolute (v_exp_f32 vs expm1f).  tanh: the exact-operation form shared with the LSTM head
+    (fe_activations.h; restated by the oracle as fo_lstm_tanh) -- the actions are the oracle's bit for bit."""
     from finenvs_amd.rollout import FusedMLPRollout
 
-    N, A, W, H = 400, 2, 32, 64
+    N, A, W = 400, 2, 32
     ref, env = _make(fe, fo, N, A, W, 5, 60, 0.05, False, seed=11)
     W1, b1, W2, b2 = _weights(W, H, seed=5)
     w1t, wpos = fo.mlp_pack(W1, W)
@@ -127,7 +130,7 @@ def test_mlp_rollout_elu_tanh_within_tolerance_in_lockstep(fe, fo, activation, a
         a_dev = t2n(acts[0])
         a_ref = fo.policy_mlp(obs, w1t, wpos, b1, W2, b2, act=act)
         worst = max(worst, float(np.abs(a_dev.astype(np.float64) - a_ref).max()))
-        np.testing.assert_allclose(a_dev, a_ref, rtol=0, atol=2e-6, err_msg=f"step {t} actions")  # tolerance: 2e-6 absolute
+        np.testing.assert_allclose(a_dev, a_ref, rtol=0, atol=atol, err_msg=f"step {t} actions")  # tolerance: 2e-6 absolute (ELU), 0 (tanh)
         obs, r_ref, d_ref, _ = ref.step(a_dev)  # lock-step on the device's actions
         obs = obs.copy()
         assert_bits(t2n(rews[0]), r_ref, f"step {t} rewards")
@@ -207,6 +210,19 @@ def test_fused_rollouts_refuse_stale_descriptors(fe, fo):
     fresh = FusedMLPRollout(env, torch.from_numpy(W1), torch.from_numpy(b1), torch.from_numpy(W2), b2, activation="relu")
     a2, r2, d2 = fresh.run(3)
     assert torch.equal(a1, a2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    # a hipGraph replay advances the env without passing through env.step(): it must count as "someone else" too
+    from finenvs_amd.rollout import GraphedRollout
+
+    env2 = fe.TimeSeriesEnv(tables=(env.price_environments.cpu().numpy(), env.log_return_environments.cpu().numpy()),
+                            num_intervals=8, num_envs=40, redraw="device", obs_buffers=1, seed=1)
+    lin2 = FusedLinearRollout(env2, torch.ones((8, 5), dtype=torch.float64) * 0.1, 0.0)
+    zeros = torch.zeros((40, 1), device=env2.device)
+    graphed = GraphedRollout(env2, lambda obs, k: zeros, 2)
+    lin2.sync_from_env()
+    lin2.run(1)
+    graphed.run()
+    with pytest.raises(RuntimeError, match="stale"):
+        lin2.run(1)
 
 
 def test_mlp_evaluation_loop_returns_match_stepwise_oracle(fe, fo):

@@ -3,7 +3,7 @@
 hipcc reports registers and scratch per kernel (-Rpass-analysis=kernel-resource-usage).  A streaming kernel that
 spills keeps part of its software pipeline in memory behind the very store stream it is trying to feed; round 2's
 f32 single-asset step kernels did (40 - 212 bytes per lane) while a comment claimed otherwise.  The table of this
-build is committed as profiles/r03_resource_usage.txt (tools/resource_usage.py --out ...).
+build is committed as profiles/r04_resource_usage.txt (tools/resource_usage.py --out ...).
 """
 import os
 import re
@@ -35,6 +35,15 @@ def test_streaming_kernels_use_no_scratch(table):
     assert not bad, f"scratch / VGPR spills in streaming kernels: {bad}"
 
 
+def test_mlp_rollout_kernels_use_no_scratch(table):
+    """H = 128 (NT = 4) kept its sleeve state in scratch memory while libm's branchy tanhf was inlined 128 times into it;
+    the tanh activation is now the exact-operation form of the LSTM head (task 7)."""
+    mlp = [r for r in table if r["name"].startswith("fe_rollout_mlp_kernel")]
+    assert len(mlp) == 6
+    bad = [(r["name"], r["scratch"], r["vgpr_spill"]) for r in mlp if r["scratch"] != 0 or r["vgpr_spill"] != 0]
+    assert not bad, f"scratch / VGPR spills in the MLP rollout kernels: {bad}"
+
+
 def test_step_kernels_keep_their_occupancy(table):
     """The launch geometry (fe_env.hip:configure_launch) assumes these wavefronts per SIMD."""
     want = {
@@ -60,7 +69,7 @@ def test_lean_step_kernel_has_fewer_scalar_spills_than_the_full_one(table):
 
 
 def test_committed_table_matches_this_build(table):
-    path = os.path.join(ROOT, "profiles", "r03_resource_usage.txt")
+    path = os.path.join(ROOT, "profiles", "r04_resource_usage.txt")
     text = open(path).read()
     for r in table:
         if r["name"].startswith(("fe_env_kernel", "fe_render_kernel")):
