@@ -367,6 +367,60 @@ def lstm_actor_case():
     save_npz(os.path.join(GOLD, "lstm_actor.npz"), **out)
 
 
+def sleeves_case(fname, name, A, N, W, T, days, bars, csv_seed, action_seed, full_obs):
+    """The multi-asset "sleeve" contract pinned to the reference: A reference
+    envs (one per asset, same calendar) stepped side by side on column a of one (N, A) action tensor.  Observation =
+    their observations concatenated along the feature axis (asset a in columns 5a..5a+4, TSE:423-445), reward = their
+    rewards added in asset order (f64), done = their common done flag."""
+    if not wanted(fname):
+        print("   (kept)", fname)
+        return
+    write_case_csv(name, days, bars, seed=csv_seed, num_assets=A)
+    envs = []
+    for a in range(A):
+        e, _ = make_env(f"{name}_a{a}", W, evaluate=True)
+        scale_env(e, N)
+        envs.append(e)
+    g = torch.Generator().manual_seed(action_seed)
+    acts, rews, dones, obss, last_rows, full_steps = [], [], [], [], [], []
+    st = {k: [] for k in ("cash", "margin", "long", "short", "spot0")}
+    obs0 = torch.cat([e.reset() for e in envs], dim=2)
+    for t in range(T):
+        a = (torch.rand((N, A), generator=g) * 2 - 1).float()
+        o_l, r_l, d_l = [], [], []
+        for k, e in enumerate(envs):
+            # evaluate mode keeps the RNG redraw out of it; clearing the metrics before each
+            # step keeps TSE:526-528 from zeroing rewards of already-terminated envs
+            e.reset_evaluation_metrics()
+            o, r, dn, _ = e.step(a[:, k : k + 1].contiguous())
+            o_l.append(o); r_l.append(r); d_l.append(dn)
+        assert all(torch.equal(d_l[0], x) for x in d_l), "sleeves must finish together in this fixture"
+        r = r_l[0]
+        for x in r_l[1:]:
+            r = r + x  # sequential sum in asset order, f64
+        acts.append(a.numpy().copy()); rews.append(r.numpy().copy()); dones.append(d_l[0].numpy().copy())
+        obs = torch.cat(o_l, dim=2).numpy().copy()
+        if full_obs or t < 3 or bool(d_l[0].any()) or t == T - 1:
+            full_steps.append(t)
+            obss.append(obs)
+        last_rows.append(obs[:, -1, :].copy())
+        for k2 in st:
+            st[k2].append(np.stack([state_of(e)[k2] for e in envs], axis=1))
+    extra = {} if full_obs else {"obs_steps": np.asarray(full_steps, dtype=np.int64), "obs_last_row": np.stack(last_rows)}
+    save_npz(
+        os.path.join(GOLD, fname),
+        W=np.int64(W), N=np.int64(N), A=np.int64(A), evaluate=np.int64(1),
+        max_shares=np.int64(5), starting_balance=np.float64(10000), commission=np.float64(0.01),
+        imr=np.float64(1.5), mmr=np.float64(0.25),
+        prices=np.concatenate([e.price_environments.numpy() for e in envs], axis=2),
+        logret=np.concatenate([e.log_return_environments.numpy() for e in envs], axis=2),
+        actions=np.stack(acts), rewards=np.stack(rews), dones=np.stack(dones), obs=np.stack(obss),
+        obs_reset=obs0.numpy(), init_env_idx=(np.arange(N) % envs[0].price_environments.shape[0]),
+        **{k2: np.stack(v) for k2, v in st.items()}, **extra,
+    )
+    print(fname, "dones=", int(np.stack(dones).sum()), "full observations at", len(full_steps), "steps")
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     setup_reference()
@@ -453,47 +507,11 @@ def main():
     save_rollout("rollout_edge_actions.npz", env, roll)
 
     # ---------------- multi-asset sleeve contract: A reference envs side by side ----------------
-    A = 3
-    write_case_csv("SYN_multi", 6, 40, seed=31, num_assets=A)
-    envs = []
-    for a in range(A):
-        e, _ = make_env(f"SYN_multi_a{a}", 8, evaluate=True)
-        scale_env(e, 20)
-        envs.append(e)
-    g = torch.Generator().manual_seed(11)
-    N = 20
-    acts, rews, dones, obss = [], [], [], []
-    st = {k: [] for k in ("cash", "margin", "long", "short", "spot0")}
-    obs0 = torch.cat([e.reset() for e in envs], dim=2)
-    for t in range(70):
-        a = (torch.rand((N, A), generator=g) * 2 - 1).float()
-        o_l, r_l, d_l = [], [], []
-        for k, e in enumerate(envs):
-            # evaluate mode keeps the RNG redraw out of it; clearing the metrics before each
-            # step keeps TSE:526-528 from zeroing rewards of already-terminated envs
-            e.reset_evaluation_metrics()
-            o, r, dn, _ = e.step(a[:, k : k + 1].contiguous())
-            o_l.append(o); r_l.append(r); d_l.append(dn)
-        assert all(torch.equal(d_l[0], x) for x in d_l), "sleeves must finish together in this fixture"
-        r = r_l[0]
-        for x in r_l[1:]:
-            r = r + x  # sequential sum in asset order, f64
-        acts.append(a.numpy().copy()); rews.append(r.numpy().copy()); dones.append(d_l[0].numpy().copy())
-        obss.append(torch.cat(o_l, dim=2).numpy().copy())
-        for k2 in st:
-            st[k2].append(np.stack([state_of(e)[k2] for e in envs], axis=1))
-    save_npz(
-        os.path.join(GOLD, "rollout_sleeves3.npz"),
-        W=np.int64(8), N=np.int64(N), A=np.int64(A), evaluate=np.int64(1),
-        max_shares=np.int64(5), starting_balance=np.float64(10000), commission=np.float64(0.01),
-        imr=np.float64(1.5), mmr=np.float64(0.25),
-        prices=np.concatenate([e.price_environments.numpy() for e in envs], axis=2),
-        logret=np.concatenate([e.log_return_environments.numpy() for e in envs], axis=2),
-        actions=np.stack(acts), rewards=np.stack(rews), dones=np.stack(dones), obs=np.stack(obss),
-        obs_reset=obs0.numpy(), init_env_idx=(np.arange(N) % envs[0].price_environments.shape[0]),
-        **{k2: np.stack(v) for k2, v in st.items()},
-    )
-    print("rollout_sleeves3.npz dones=", int(np.stack(dones).sum()))
+    sleeves_case("rollout_sleeves3.npz", "SYN_multi", A=3, N=20, W=8, T=70, days=6, bars=40, csv_seed=31, action_seed=11, full_obs=True)
+    # BASELINE configs 3-5 are 30-asset portfolios: the (N, W, 150) observation layout, reward = sum in asset order and the
+    # shared done flag of that shape against 30 reference envs on one calendar (crosses a day end; no bankruptcies, so the
+    # side-by-side references stay in step).  Full observations at a few steps, the newest window row at every step.
+    sleeves_case("rollout_sleeves30.npz", "SYN_multi30", A=30, N=9, W=8, T=64, days=5, bars=40, csv_seed=47, action_seed=29, full_obs=False)
 
     # ---------------- rounding probes (a3) ----------------
     env, _ = make_env("SYN_roll", 8, evaluate=True)

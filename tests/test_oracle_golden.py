@@ -132,24 +132,34 @@ def test_real_data_ibm_spy_rollouts(name):
     _replay(g, name, host_redraw=True, check_obs_full=False)
 
 
-def test_multi_asset_sleeves_equal_side_by_side_references():
-    g = load_golden("rollout_sleeves3.npz")
+@pytest.mark.parametrize("name", ["rollout_sleeves3.npz", "rollout_sleeves30.npz"])
+def test_multi_asset_sleeves_equal_side_by_side_references(name):
+    """The oracle's sleeve loop against A reference envs stepped side by side; rollout_sleeves30.npz = the 30-asset
+    shape of BASELINE configs 3-5 (full observations at `obs_steps`, the newest window row at every step)."""
+    g = load_golden(name)
     W, N, A = int(g["W"]), int(g["N"]), int(g["A"])
     env = fo.OracleEnv(g["prices"], g["logret"], W, evaluate=True, env_indices=g["init_env_idx"], **econ_kwargs(g))
     assert env.A == A
     assert_bits(env.reset(), g["obs_reset"], "reset obs")
+    full_at = {int(t): i for i, t in enumerate(g["obs_steps"])} if "obs_steps" in g else None
     for t in range(g["actions"].shape[0]):
         obs, rew, done, _ = env.step(g["actions"][t])
         env.terminated[:] = 0  # the fixture cleared the metrics each step
         env.n_terminated[0] = 0
         what = f"sleeves step {t}"
-        assert_bits(obs, g["obs"][t], what + " obs")
+        if full_at is None:
+            assert_bits(obs, g["obs"][t], what + " obs")
+        else:
+            assert_bits(np.ascontiguousarray(obs[:, -1, :]), g["obs_last_row"][t], what + " newest window row")
+            if t in full_at:
+                assert_bits(obs, g["obs"][full_at[t]], what + " obs")
         assert_bits(rew, g["rewards"][t], what + " rewards")
         assert_bits(done, g["dones"][t], what + " dones")
         assert_bits(env.cash, g["cash"][t], what + " cash")
         assert_bits(env.margin, g["margin"][t], what + " margin")
         assert_bits(env.long, g["long"][t], what + " long")
         assert_bits(env.short, g["short"][t], what + " short")
+    assert g["dones"].sum() > 0
 
 
 def test_share_change_rounding_probes():
