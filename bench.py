@@ -52,7 +52,8 @@ CONFIGS = {
 }
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 TRAJ_T = 16             # trajectory slots on one GPU (no exchange)
-AUDITION_EXTRA = 10     # ring audition: candidate buffers beyond the ring's own (config 3: 12 x 20 GB fit; config 5: 1; config 4: none)
+AUDITION_EXTRA = 10     # ring audition: at most this many candidate buffers beyond the ring's own ...
+AUDITION_BUDGET = 48 << 30  # ... and at most this many bytes of them (config 2: 10 x 168 MB; config 3: 2 x 20 GB; configs 4 / 5: none)
 TRAJ_BUDGET = 48e9      # bytes of trajectory chunks + gathered copies a rank may hold (N > 1)
 # the reference's own PyTorch-CPU path, measured in the build container
 REFERENCE_CPU_QUOTED = {"value": 40497, "unit": "env-steps/s", "cores": 8,
@@ -147,6 +148,17 @@ def is_step_kernel(name: str) -> bool:
     return re.search(r"fe_env_kernel<[^>]*, (?:true|false), false, \d+>", name) is not None
 
 
+def step_kernel_name(W: int, A: int, f32: bool, form: int) -> str:
+    """The demangled instantiation fe_env_kernel<OT, VEC, SINGLE, RESET_ONLY, FORM> a step launch dispatches to (as
+    rocprofv3's kernel trace names it, minus the anonymous namespace): OT / VEC as fe_env_create picks them (16-byte
+    packs unless W*5*A is odd), FORM 0 lean (plain fe_env_step), 1 full (trajectory outputs / statistics / evaluate
+    mode), 2 / 3 the same with the host flag (redraw='torch')."""
+    vec = 4 if f32 else 2
+    while vec > 1 and (W * 5 * A) % vec:
+        vec //= 2
+    return f"fe_env_kernel<{'float' if f32 else 'double'}, {vec}, {'true' if A == 1 else 'false'}, false, {form}>"
+
+
 def under_profiler(environ=None) -> bool:
     """True when THIS process already runs under rocprofv3 / a rocprofiler tool library.  A nested
     `rocprofv3 --pmc` would inherit the preloaded tool library: it initialises the GPU in the child launcher, which
@@ -235,8 +247,9 @@ def pmc_child(args):
     prices, day_id, _ = make_series(A)
     obs_bytes = N * W * 5 * A * (4 if args.obs_f32 else 8)
     env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw=args.redraw, seed=1234,
-                                    obs_buffers=2 if 2 * obs_bytes < 200e9 else 1, obs_audition=0 if args.no_audition else AUDITION_EXTRA,
-                                    obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+                                    obs_buffers=2 if 2 * obs_bytes < 200e9 else 1, obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+    if not args.no_audition:
+        env.audition_ring(AUDITION_EXTRA, AUDITION_BUDGET)
     g = torch.Generator(device="cuda:0").manual_seed(7)
     actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
     env.reset()
@@ -423,16 +436,6 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         N = env.num_envs
         g = torch.Generator(device=dev).manual_seed(7 + rank)
         actions = [(torch.rand((N, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
-        # The ring as the allocator handed it out is timed FIRST (`as_allocated`); then ring mode's placement audition (a
-        # product feature of the ring) tries up to AUDITION_EXTRA more candidate buffers (as far as free memory allows) and keeps the fastest
-        # (none fit at config 4) -- the headline runs on the auditioned ring, the as-allocated figure is reported beside it.
-        as_allocated = None
-        if not args.no_audition:
-            env.reset()
-            k_aa = launches_per_run(env, actions, steps)
-            kernel_interval_ms(env, actions, k_aa, runs=1)  # discarded: clocks, tables and state warm before anything is compared
-            as_allocated = {"kernel_ms": kernel_interval_ms(env, actions, k_aa, runs=3)}
-            env.audition_ring(AUDITION_EXTRA)
         # Compact trajectory fields live in a device buffer; the step kernel writes rewards, dones and its copy of the
         # actions straight into slot t (fe_env_step_traj), so storing a step costs no extra launch.  (Round 2 found the
         # earlier scheme -- actions pre-stored in the slots -- to read 256 KB of COLD memory per step once a chunk is longer
@@ -515,6 +518,44 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     fence()
     est = D.max_over_ranks(time.perf_counter() - t0) / min(steps, 8)
     R = auto_repeats(repeats, steps, est)
+    total_envs = env.global_num_envs if world > 1 else N
+
+    # The ring AS THE ALLOCATOR HANDED IT OUT is timed first, with the headline's own loop and fences (`as_allocated`: wall
+    # value + kernel interval); then ring mode's placement audition (a product feature of the ring)
+    # tries a BOUNDED number of further candidate buffers (AUDITION_EXTRA / AUDITION_BUDGET) and keeps the fastest -- the
+    # headline runs on the auditioned ring.  Where no candidate fits (configs 4 and 5) both figures are the same run.
+    as_allocated = None
+    if not args.no_audition and roll is None:
+        if D.multi:
+            gather[0] = True
+            fence()
+            traj.clear()
+            run_steps(T)  # one full chunk: the first timed block has something to gather
+        aa_blocks = timed_blocks(R)
+        k_aa = launches_per_run(env, actions, steps)
+        aa_kern = kernel_interval_ms(env, actions, k_aa, runs=3)
+        ring_before = [t.data_ptr() for t in env._obs_ring]
+        env.audition_ring(AUDITION_EXTRA, AUDITION_BUDGET)
+        changed = [t.data_ptr() for t in env._obs_ring] != ring_before
+        aa_block = statistics.median(aa_blocks)
+        as_allocated = {"value": total_envs * steps / aa_block, "ms_per_step": aa_block / steps * 1e3,
+                        "ms_per_step_min": min(aa_blocks) / steps * 1e3, "ms_per_step_max": max(aa_blocks) / steps * 1e3,
+                        "blocks": len(aa_blocks), "kernel_ms": aa_kern,
+                        "frac_of_8TBps_wall": hbm_bytes(W, A, obs_elem) * N / (aa_block / steps) / 1e9 / HBM_PEAK_GBPS,
+                        "frac_of_8TBps_kernel": hbm_bytes(W, A, obs_elem) * N / (aa_kern * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                        "ring_changed_by_audition": changed,
+                        "what": "the same timed loop and fences as `value`, on the observation ring as the allocator handed it out "
+                                "(before the placement audition)"}
+        # warm the (possibly new) buffers: first touch, translations.  Unconditional and without collectives: the ranks
+        # of an N > 1 run may keep different buffers, but must stay in step
+        gather[0] = False
+        fence()
+        traj.clear()
+        env.reset()
+        run_steps(max(min(warmup, steps), 4))
+        fence()
+        traj.clear()
+        gather[0] = D.multi
     legs = {}
     if D.multi:
         gather[0] = True
@@ -556,7 +597,6 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     kern = kernel_interval_ms(env, actions, k2, runs=3, all_runs=True)
     kern_ms = statistics.median(kern)
 
-    total_envs = env.global_num_envs if world > 1 else N
     Bh = hbm_bytes(W, A, obs_elem)
     Bs = survey_bytes(W, A) - (4 * W * 5 * A if args.obs_f32 else 0)
     l2_read = (16 if args.obs_f32 else 32) * W * A  # window re-read per env-step, served by L2 / Infinity Cache
@@ -579,7 +619,15 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-            "kernel": "fe_env_kernel (fused step)", "kernel_ms": kern_ms,
+            # the instantiation kernel_interval_ms launches (fe_env_step_traj: the full form) -- the row to look up in
+            # profiles/*_kernel_stats.csv; the timed loop (env.step with trajectory slots) launches the same one, or with
+            # redraw='torch' its host-flag variant (FORM 3: same arithmetic, last tile first)
+            "kernel": step_kernel_name(W, A, args.obs_f32, 1),
+            "timed_loop_kernel": step_kernel_name(W, A, args.obs_f32, 3 if (args.redraw == "torch" and env._flag is not None) else 1),
+            "kernel_ms": kern_ms,
+            "kernel_ms_regime": "tight loop: back-to-back C-ABI launches, one HIP-event pair around the train (kernel + the ~1.5 us "
+                                "launch boundary); Python-paced launches of the timed loop run the same kernel 5 - 10 % longer "
+                                "(XCDs wake up staggered after every gap, DESIGN.md section 5)",
             "kernel_ms_runs": kern, "kernel_launches_per_run": k2,
             # `achieved` counts only bytes that must cross HBM (observation write + state + outputs):
             "hbm_bytes_per_env_step": Bh, "units_per_launch": N,
@@ -859,12 +907,12 @@ def main():
             "config": {"workload": head["workload"], "envs_per_gpu": head["envs_per_gpu"],
                        "num_assets": head["num_assets"], "window": head["window"],
                        "obs_buffers": head["obs_buffers"], "obs_ring_audition": head["obs_ring_audition"],
-                       # the ring as allocated, timed before the placement audition (kernel interval and the same on the wall)
-                       "as_allocated_ms_per_step": (head["as_allocated"] or {}).get("kernel_ms"),
-                       "auditioned_kernel_ms_per_step": head["roofline"]["kernel_ms"],
+                       "obs_ring_audition_bound": {"extra_candidates": AUDITION_EXTRA, "budget_bytes": AUDITION_BUDGET},
                        "eval_redraw": args.redraw, "redraw_contract": REDRAW_CONTRACT,
                        "launch_mode": head["launch_mode"], "launch": head["launch"],
                        "timed_region": "median of R blocks of exactly `steps` steps, each between (barrier + synchronize) fences, max over ranks per block"},
+            # the un-auditioned regime beside the headline: same loop, same fences, the ring as the allocator handed it out
+            "as_allocated": head["as_allocated"],
             "repeats": head["repeats"],
             "roofline": head["roofline"],
             "cpu_baseline": head.get("cpu_baseline"),

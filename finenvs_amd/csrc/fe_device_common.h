@@ -23,7 +23,15 @@ constexpr int kMultiAssetWaves = 6;
 //     34.5 -> 32.0, 34.8 -> 33.6 us per step; nt gains about 1 % less, sc0|sc1 the same.
 //   * multi-asset envs: nt.  Measured at 1M envs x 30 assets (profiles/r01_microbench/store_policy.txt): FETCH_SIZE
 //     6.9 GiB -> 0.4 GiB per launch and 26.4 -> 25.0 ms; sc1 gives the same fetch reduction but 25.6 ms.
+//   * single-asset envs whose observation RING does not fit the 256 MiB Infinity Cache (round 4): sc1 | nt.  Back-to-back
+//     launches into ONE 168 MB buffer run 27.5 us, alternating over two (336 MB) 29.1 us, A,A,B,B 27.7 us
+//     (profiles/r04_microbench/ring_alternation.txt): the memory-side cache absorbs a rewritten buffer and thrashes on a
+//     ring larger than itself.  nt on top of sc1 keeps the stream out of it: 64k envs x W64 f64 (ring 336 MB) 29.73 ->
+//     28.93 and 28.84 -> 28.21 us on two boxes; with f32 observations (ring 168 MB, fits) the same bits cost +8.9 %, and
+//     at 256k x 30 assets sc1 | nt instead of nt is +0.5 % (profiles/r04_microbench/ab_store_aux.txt).  The host decides per
+//     env (fe_env.hip: Params::obs_stream = one observation buffer >= 128 MiB, i.e. two of them overflow the cache).
 constexpr int kStoreAuxSingle = 16;
+constexpr int kStoreAuxSingleStream = 16 | 2;
 constexpr int kStoreAuxMulti = 2;
 // "" for the product library; experiment builds (finenvs_amd/csrc/build.py build_variant) carry their -D set here
 // and are only ever loaded by explicit path
@@ -112,6 +120,7 @@ struct Params {
     int32_t W, A, EB;
     int32_t evaluate, redraw_mode;
     uint32_t env_elems;  // W * 5 * A, observation elements per env
+    int32_t obs_stream;  // single-asset envs: 1 = the observation ring is larger than the Infinity Cache (stores sc1 | nt)
     FastDiv div_WA;  // by tuples per env (W * A)
     FastDiv div_A;
     float scale32, ms32, c32, imr32, S32;

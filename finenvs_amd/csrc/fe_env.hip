@@ -390,6 +390,9 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
     p.evaluate = cfg->evaluate ? 1 : 0;
     p.redraw_mode = cfg->redraw_mode;
     p.env_elems = (uint32_t)env_elems;
+    // One observation buffer of 128 MiB or more: a ring of two (or the allocator's recycled blocks behind fresh tensors)
+    // overflows the 256 MiB Infinity Cache, and the store stream is better kept out of it (fe_device_common.h, store policy)
+    p.obs_stream = cfg->A == 1 && cfg->N * env_elems * (cfg->obs_is_f32 ? 4 : 8) >= (128ll << 20) ? 1 : 0;
     p.div_WA = make_fastdiv((uint32_t)((int64_t)cfg->W * cfg->A));
     p.div_A = make_fastdiv((uint32_t)A);
     p.scale32 = (float)((double)cfg->max_shares + 0.5);

@@ -267,6 +267,9 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
             // wavefront's 5-KiB slab; the descriptor is wave-uniform
             using u4 = __attribute__((ext_vector_type(4))) unsigned int;
             constexpr int kAux = SINGLE ? kStoreAuxSingle : kStoreAuxMulti;
+            // single-asset envs whose observation ring cannot live in the 256 MiB Infinity Cache stream past it
+            // (sc1 | nt, p.obs_stream): one uniform branch around the whole store group, straight-line stores inside
+            const bool stream_past_mall = SINGLE && p.obs_stream != 0;
             const uint64_t basep = reinterpret_cast<uint64_t>(o);
             const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)basep);
             const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(basep >> 32));
@@ -277,12 +280,20 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
             // 16 bytes, like every pack offset), and the buffer range check drops the lanes past it -- straight-line
             // reads and stores, one LDS address and one store offset register instead of five each.
             const u4 *rd4 = reinterpret_cast<const u4 *>(stage) + lane;
+            if (stream_past_mall) {
 #pragma unroll
-            for (int i = 0; i < kStores; ++i) {
-                __builtin_amdgcn_raw_buffer_store_b128(rd4[64 * i], rsrc, (uint32_t)lane * 16u + 1024u * i, 0, kAux);
-                // image read -> store, one pack at a time: with all five reads issued first the stores leave as one
-                // burst, measured 0 - 2 % slower at 64k envs (profiles/r03_microbench/ab_store_form.txt)
-                __builtin_amdgcn_sched_barrier(0);
+                for (int i = 0; i < kStores; ++i) {
+                    __builtin_amdgcn_raw_buffer_store_b128(rd4[64 * i], rsrc, (uint32_t)lane * 16u + 1024u * i, 0, kStoreAuxSingleStream);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < kStores; ++i) {
+                    __builtin_amdgcn_raw_buffer_store_b128(rd4[64 * i], rsrc, (uint32_t)lane * 16u + 1024u * i, 0, kAux);
+                    // image read -> store, one pack at a time: with all five reads issued first the stores leave as one
+                    // burst, measured 0 - 2 % slower at 64k envs (profiles/r03_microbench/ab_store_form.txt)
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         } else {
             // observation sizes that are not a multiple of 16 bytes (odd W * A): 8- / 4-byte stores, plain cache policy;

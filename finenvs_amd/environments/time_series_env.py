@@ -14,7 +14,7 @@ Keyword-only extensions: ``num_envs`` (env n -> day n mod D), ``num_assets`` /
 ``prices`` / ``day_id`` (tensor input, multi-asset "sleeve" contract of
 DESIGN.md), ``tables`` (ready-made (D,L,4A) price/log-return tables),
 ``obs_dtype``, ``cast_actions`` (accept non-f32 actions by casting; default: ValueError), ``obs_buffers`` (opt-in ring of env-owned observation buffers), ``obs_audition`` (ring mode:
-extra candidate buffers to try at construction, the fastest stay), ``redraw``, ``seed``, ``env_indices``, ``rank`` /
+extra candidate buffers to try at construction -- within a quarter of the free memory --, the fastest stay), ``redraw``, ``seed``, ``env_indices``, ``rank`` /
 ``world_size`` (contiguous env shards, one process per GPU).
 """
 from __future__ import annotations
@@ -324,19 +324,24 @@ class TimeSeriesEnv:
         # own observation descriptors and refuse to run on ones that another caller has made stale (rollout.py)
         self._generation = 0
 
-    def audition_ring(self, extra: int) -> None:
+    def audition_ring(self, extra: int = 2, budget_bytes: Optional[int] = None) -> None:
         """Ring mode only (also what ``obs_audition=`` runs at construction).  HBM write bandwidth on MI355X depends on where a buffer lies (the same store kernel runs
         5.7 ... 6.5 TB/s on different 20 GB allocations, reproducibly per buffer; tools/placement.hip, DESIGN.md
         section 4), and the step kernel is bound by exactly that.  So: allocate up to ``extra`` more candidate
-        buffers than the ring needs (as far as free memory allows), time the observation render into each, keep
-        the fastest ``obs_buffers`` and give the rest back.  Values are unaffected; ``self.obs_audition`` records
-        what was measured."""
+        buffers than the ring needs, time the observation render into each, keep the fastest ``obs_buffers`` and give
+        the rest back.  Values are unaffected; ``self.obs_audition`` records what was measured.
+
+        The audition is BOUNDED: at most ``extra`` candidates (default 2), together at most ``budget_bytes`` (default:
+        one quarter of the memory that is free right now), and never into the last 8 GiB of free memory -- constructing
+        a 20-GB-per-buffer env must not transiently hold the whole card (12 x 20 GB at config 3)."""
         if self.obs_buffers < 1:
             raise ValueError("audition_ring needs ring mode (obs_buffers >= 1)")
         N, W, A = self.num_envs, self.num_intervals, self.num_assets
         nbytes = N * W * 5 * A * (4 if self.obs_dtype == torch.float32 else 8)
         free, _ = torch.cuda.mem_get_info(self._dev)
-        extra = int(max(0, min(extra, (free - (8 << 30)) // max(nbytes, 1))))
+        budget = free // 4 if budget_bytes is None else int(budget_bytes)
+        budget = max(0, min(budget, free - (8 << 30)))
+        extra = int(max(0, min(int(extra), budget // max(nbytes, 1))))
         cands = list(self._obs_ring)
         try:
             for _ in range(extra):
@@ -344,7 +349,7 @@ class TimeSeriesEnv:
         except RuntimeError:  # out of memory: audition what we have
             pass
         if len(cands) <= self.obs_buffers:
-            self.obs_audition = {"candidates": len(cands), "us": [], "kept": list(range(len(cands)))}
+            self.obs_audition = {"candidates": len(cands), "us": [], "kept": list(range(len(cands))), "budget_bytes": budget}
             return
         st = self._stream()
         times = []
@@ -362,7 +367,8 @@ class TimeSeriesEnv:
         order = sorted(range(len(cands)), key=lambda i: times[i])
         kept = sorted(order[: self.obs_buffers])
         self._obs_ring = [cands[i] for i in kept]
-        self.obs_audition = {"candidates": len(cands), "us": [round(t, 2) for t in times], "kept": kept}
+        self._obs_next = 0
+        self.obs_audition = {"candidates": len(cands), "us": [round(t, 2) for t in times], "kept": kept, "budget_bytes": budget}
         del cands
         torch.cuda.empty_cache()
 

@@ -35,4 +35,10 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.05  # the kernel cannot take longer than the wall step (5 % timing slack)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and "sample" in c
-    assert d["config"]["as_allocated_ms_per_step"] > 0 and "redraw_contract" in d["config"]
+    assert "redraw_contract" in d["config"]
+    assert r["kernel"] == "fe_env_kernel<double, 2, true, false, 1>"  # the instantiation the timed loop launches
+    # the un-auditioned regime is in the line too: same loop and fences on the ring as allocated
+    aa = d["as_allocated"]
+    assert aa["value"] > 0 and aa["kernel_ms"] > 0 and aa["blocks"] >= 3
+    assert abs(aa["value"] - 65536 / (aa["ms_per_step"] * 1e-3)) / aa["value"] < 1e-6
+    assert d["config"]["obs_ring_audition"]["candidates"] <= 2 + d["config"]["obs_ring_audition_bound"]["extra_candidates"]
