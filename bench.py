@@ -494,6 +494,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     trace = os.environ.get("FE_BENCH_TRACE") == "1"  # stderr: where a timed block's wall time goes (host issue / drain / fence)
 
     def timed_blocks(r):
+        """r blocks of exactly `steps` steps, each bracketed by a full fence (drain + synchronize + barrier + synchronize) on
+        both sides, as the driver's contract says; the block's time is the MAX over ranks."""
         out = []
         for _ in range(r):
             fence()
@@ -910,7 +912,11 @@ def main():
                        "obs_ring_audition_bound": {"extra_candidates": AUDITION_EXTRA, "budget_bytes": AUDITION_BUDGET},
                        "eval_redraw": args.redraw, "redraw_contract": REDRAW_CONTRACT,
                        "launch_mode": head["launch_mode"], "launch": head["launch"],
-                       "timed_region": "median of R blocks of exactly `steps` steps, each between (barrier + synchronize) fences, max over ranks per block"},
+                       "timed_region": "median of R blocks of exactly `steps` steps, each between (drain + synchronize + barrier + synchronize) "
+                                       "fences, MAX over ranks per block.  A block of --steps 20 at 64k envs is ~0.6 ms: the idle-GPU start of "
+                                       "every block (staggered XCD wake-up), the closing fence (N > 1: one barrier, tens of microseconds) and "
+                                       "fe_env_step's Python make `ms_per_step` ~5 % longer than `roofline.kernel_ms`, the launch interval of "
+                                       "long back-to-back trains"},
             # the un-auditioned regime beside the headline: same loop, same fences, the ring as the allocator handed it out
             "as_allocated": head["as_allocated"],
             "repeats": head["repeats"],

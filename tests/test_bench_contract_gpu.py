@@ -42,3 +42,66 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     assert aa["value"] > 0 and aa["kernel_ms"] > 0 and aa["blocks"] >= 3
     assert abs(aa["value"] - 65536 / (aa["ms_per_step"] * 1e-3)) / aa["value"] < 1e-6
     assert d["config"]["obs_ring_audition"]["candidates"] <= 2 + d["config"]["obs_ring_audition_bound"]["extra_candidates"]
+
+
+def _one_json_line(out):
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {out.stdout[:500]}"
+    return json.loads(lines[0])
+
+
+def _check_multi_gpu_object(m, ranks):
+    for key in ("ranks_seen", "collective_backend", "trajectory_slots", "packed_bytes_per_rank_per_chunk", "value_with_all_gather",
+                "value_no_all_gather", "gather_only_ms", "gather_only_ms_per_step_if_exposed", "exposed_ms_per_step"):
+        assert key in m, key
+    assert m["ranks_seen"] == ranks
+    assert m["value_with_all_gather"] > 0 and m["value_no_all_gather"] > 0 and m["gather_only_ms"] > 0
+    assert m["gathered_bytes_per_rank_per_chunk"] == ranks * m["packed_bytes_per_rank_per_chunk"]
+
+
+def test_bench_n_gt_1_code_path_over_rccl_with_one_rank():
+    """bench.py's N > 1 path -- RCCL process group, asynchronous trajectory all-gather legs, gather-only leg, the config-5
+    rank shard -- with the one rank a one-GPU box allows (FE_BENCH_FORCE_DIST=1: a rehearsal knob the driver never sets).
+    The first execution with more than one RCCL rank happens on the driver's 8-GPU node; everything but the transport is
+    exercised here."""
+    env = dict(os.environ, FE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29537")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-pmc"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    d = _one_json_line(out)
+    assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["cpu_baseline"] is None  # (the CPU leg belongs to the plain N = 1 line)
+    assert d["multi_gpu"]["collective_backend"] == "nccl"
+    _check_multi_gpu_object(d["multi_gpu"], 1)
+    assert "rccl" in d["multi_gpu"] and d["multi_gpu"]["rccl"] is not None
+    # value is the with-all-gather leg
+    assert abs(d["value"] - d["multi_gpu"]["value_with_all_gather"]) / d["value"] < 1e-9
+    assert set(d["repeats"]) == {"with_all_gather", "no_all_gather"}
+    # N > 1 runs carry exactly one extra leg: the per-GPU shard of config 5 (4M envs over 8 GPUs), error-free
+    assert len(d["extra_configs"]) == 1
+    c5 = d["extra_configs"][0]
+    assert "error" not in c5, c5.get("error")
+    assert c5["config"] == 5 and c5["envs_per_gpu"] == 524288 and c5["num_assets"] == 30 and c5["window"] == 128
+    _check_multi_gpu_object(c5["multi_gpu"], 1)
+    assert c5["multi_gpu"]["packed_bytes_per_rank_per_chunk"] == c5["multi_gpu"]["trajectory_slots"] * 524288 * (8 + 4 * 30 + 4)
+    assert 0.3 < c5["roofline"]["frac"] < 1.0
+
+
+def test_bench_two_ranks_through_torch_distributed_run():
+    """The driver's launch line for N = 2 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
+    127.0.0.1 ... bench.py --gpus 2 ...`) on a one-GPU box: both ranks on device 0 over gloo (FE_BENCH_SINGLE_DEVICE /
+    FE_BENCH_BACKEND: rehearsal knobs the driver never sets).  The launcher is started from a process that has not touched
+    the GPU.  Checks the rank plumbing (RANK / LOCAL_RANK / WORLD_SIZE from the env), the sharded env (the evaluation env on
+    the last rank), the collective legs with two real ranks, max-over-ranks timing, and that only rank 0 prints.  The config-5
+    leg is skipped here: two ranks' shards (2 x 154 GB) do not fit one card."""
+    env = dict(os.environ, FE_BENCH_SINGLE_DEVICE="1", FE_BENCH_BACKEND="gloo", FE_BENCH_NO_EXTRA="1")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", "29541", os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-pmc"],
+                         capture_output=True, text=True, timeout=900, env=env, cwd=REPO)
+    d = _one_json_line(out)
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak"
+    _check_multi_gpu_object(d["multi_gpu"], 2)
+    assert d["multi_gpu"]["collective_backend"] == "gloo"
+    # weak scaling: every rank owns the config's full env count; value counts all ranks' envs
+    assert d["config"]["envs_per_gpu"] == 65536
+    assert abs(d["value"] - 2 * 65536 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert d["extra_configs"] == []

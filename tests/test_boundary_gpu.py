@@ -212,6 +212,14 @@ def test_ring_audition_changes_placement_only(fe, fo):
         o, r, d, _ = env.step(a.to(env.device))
         o2, r2, d2, _ = ref.step(a.numpy())
         assert_bits(t2n(o), o2, f"step {t} obs"); assert_bits(t2n(r), r2, f"step {t} rewards"); assert_bits(t2n(d), d2, f"step {t} dones")
+    # the audition is bounded in bytes as well as in candidates, and a candidate must beat a ring member by min_gain
+    nbytes = N * W * 5 * A * 8
+    before = [t.data_ptr() for t in env._obs_ring]
+    env.audition_ring(extra=8, budget_bytes=3 * nbytes + 100, min_gain=1.0)  # nothing is 100 % faster: the ring stays
+    assert env.obs_audition["candidates"] == 2 + 3 and env.obs_audition["kept"] == [0, 1]
+    assert [t.data_ptr() for t in env._obs_ring] == before
+    env.audition_ring(extra=8, budget_bytes=0)
+    assert env.obs_audition["candidates"] == 2 and env.obs_audition["us"] == []
     plain = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_audition=4)  # fresh-tensor mode: ignored
     assert not hasattr(plain, "obs_audition") and plain._obs_ring == []
 
