@@ -55,6 +55,7 @@ TRAJ_T = 16             # trajectory slots on one GPU (no exchange)
 AUDITION_EXTRA = 10     # ring audition: at most this many candidate buffers beyond the ring's own ...
 AUDITION_BUDGET = 48 << 30  # ... and at most this many bytes of them (config 2: 10 x 168 MB; config 3: 2 x 20 GB; configs 4 / 5: none)
 TRAJ_BUDGET = 48e9      # bytes of trajectory chunks + gathered copies a rank may hold (N > 1)
+SETTLE_MS = 20.0        # untimed steps before every timed phase: the box's clock transient after an idle period (run_workload.settle)
 # the reference's own PyTorch-CPU path, measured in the build container
 REFERENCE_CPU_QUOTED = {"value": 40497, "unit": "env-steps/s", "cores": 8,
                         "what": "hmomin/FinEnvs TimeSeriesEnv.step, torch 2.10 CPU, 65536 envs x W64, build container"}
@@ -522,11 +523,29 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     R = auto_repeats(repeats, steps, est)
     total_envs = env.global_num_envs if world > 1 else N
 
+    def settle():
+        """Untimed steps for SETTLE_MS of GPU time, straight before a timed phase.  After an idle period (env construction,
+        allocations, the audition's event waits) this pool's GPUs run the same kernel at its settled duration for ~1 ms, then
+        15 - 25 % longer for several ms, and are back after ~14 ms (profiles/r04_microbench/idle_transient.txt; identical for
+        C-ABI trains and the Python loop): a 0.6 ms block timed inside that window measures the box's clock transient.  A
+        rollout runs for minutes; the timed region is to describe that regime.  Same count on every rank, no collectives."""
+        n = int(min(2000, max(0, round(SETTLE_MS * 1e-3 / max(est, 1e-9)))))
+        n = (n + 7) // 8 * 8 if roll is not None else n
+        keep = gather[0]
+        gather[0] = False
+        run_steps(n)
+        gather[0] = keep
+        return n
+
+    settle_steps = settle()
+
     # The ring AS THE ALLOCATOR HANDED IT OUT is timed first, with the headline's own loop and fences (`as_allocated`: wall
     # value + kernel interval); then ring mode's placement audition (a product feature of the ring, DESIGN.md section 4)
     # tries a BOUNDED number of further candidate buffers (AUDITION_EXTRA / AUDITION_BUDGET) and keeps the fastest -- the
-    # headline runs on the auditioned ring.  Where no candidate fits (configs 4 and 5) both figures are the same run.
+    # headline runs on the auditioned ring.  Where the audition keeps the ring as it was (no candidate fits: configs 4 and 5;
+    # none is > 3 % faster: usually config 2) both figures are the same timed blocks.
     as_allocated = None
+    reuse_blocks = None  # the as-allocated blocks ARE the headline's when the audition kept the ring (on every rank)
     if not args.no_audition and roll is None:
         if D.multi:
             gather[0] = True
@@ -548,6 +567,9 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
                         "ring_changed_by_audition": changed,
                         "what": "the same timed loop and fences as `value`, on the observation ring as the allocator handed it out "
                                 "(before the placement audition)"}
+        if D.all_ok(not changed):
+            reuse_blocks = aa_blocks
+            as_allocated["same_run_as_value"] = True
         # warm the (possibly new) buffers: first touch, translations.  Unconditional and without collectives: the ranks
         # of an N > 1 run may keep different buffers, but must stay in step
         gather[0] = False
@@ -558,13 +580,14 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         fence()
         traj.clear()
         gather[0] = D.multi
+        settle()
     legs = {}
     if D.multi:
         gather[0] = True
         fence()
         traj.clear()
         run_steps(T)  # one full chunk: the first timed block has something to gather
-        legs["with_all_gather"] = timed_blocks(R)
+        legs["with_all_gather"] = reuse_blocks if reuse_blocks is not None else timed_blocks(R)
         fence()
         gather[0] = False
         traj.clear()
@@ -589,7 +612,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         fence()
         traj.clear()
     else:
-        legs["single_gpu"] = timed_blocks(R)
+        legs["single_gpu"] = reuse_blocks if reuse_blocks is not None else timed_blocks(R)
         head = legs["single_gpu"]
     block = statistics.median(head)
 
@@ -614,6 +637,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         "as_allocated": as_allocated,
         "launch": env.launch_info(),
         "launch_mode": "hipGraph x8 steps" if args.graph else "eager, one launch per step",
+        "settle_steps": settle_steps,
         "repeats": {name_: {"blocks": len(v), "ms_per_step_median": statistics.median(v) / steps * 1e3,
                             "ms_per_step_min": min(v) / steps * 1e3, "ms_per_step_max": max(v) / steps * 1e3,
                             "value_median": total_envs * steps / statistics.median(v)}
@@ -694,7 +718,7 @@ def two_stream_leg(args, steps: int):
         e0.record()
         for s_ in streams:
             s_.wait_event(e0)
-        for k in range(k2):
+        for k in range(k2 if rep else 4 * k2):  # the discarded first run also carries the GPU past its post-idle clock transient
             for (env, acts, rew, done), s_ in zip(parts, streams):
                 rc = env._step_fn(env._handle_v, acts[k % 8].data_ptr(), env._obs_ring[k % 2].data_ptr(), rew.data_ptr(), done.data_ptr(),
                                   s_.cuda_stream)
@@ -739,7 +763,7 @@ def reference_semantics_leg(args, steps: int, repeats: int = 5):
     g = torch.Generator(device="cuda:0").manual_seed(7)
     actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
     states = env.reset()
-    for i in range(20):
+    for i in range(20 + int(SETTLE_MS / 0.03)):  # warm-up + the clock transient after the idle period of construction (run_workload.settle)
         states, _, _, _ = env.step(actions[i % 8])
     blocks = []
     for _ in range(repeats):
@@ -912,6 +936,10 @@ def main():
                        "obs_ring_audition_bound": {"extra_candidates": AUDITION_EXTRA, "budget_bytes": AUDITION_BUDGET},
                        "eval_redraw": args.redraw, "redraw_contract": REDRAW_CONTRACT,
                        "launch_mode": head["launch_mode"], "launch": head["launch"],
+                       "untimed_steps_before_timing": {"warmup": head["warmup"], "settle": head["settle_steps"],
+                                                       "why": f"{SETTLE_MS:g} ms of steps straight before each timed phase: after an idle period the GPU "
+                                                              "runs the same kernel 15 - 25 % slower for ~10 ms (clock transient, "
+                                                              "profiles/r04_microbench/idle_transient.txt)"},
                        "timed_region": "median of R blocks of exactly `steps` steps, each between (drain + synchronize + barrier + synchronize) "
                                        "fences, MAX over ranks per block.  A block of --steps 20 at 64k envs is ~0.6 ms: the idle-GPU start of "
                                        "every block (staggered XCD wake-up), the closing fence (N > 1: one barrier, tens of microseconds) and "

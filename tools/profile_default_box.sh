@@ -17,6 +17,6 @@ lines += ["", "| kernel | calls | avg us | min us | max us | % of GPU time |", "
 for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"]))[:8]:
     lines.append(f"| `{r['Name'].replace('(anonymous namespace)::', '')[:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
 lines += ["", "(`fe_env_kernel<double, 2, true, false, 1>` is the config-2 step kernel as bench.py's loop launches it (trajectory outputs: the full form; `..., false, 0>` = the lean form of a plain env.step -- here the two_streams leg's overlapping launches --, `2` / `3` = lean / full + host flag: the reference_semantics leg); `<double, 2, false, false, *>` serves configs 3, 4 and 5 in the same process, so its average mixes 3.5, 12.7 and 25 ms launches.)"]
-open(os.path.join(os.path.dirname(out), "..", "profiles", f"{tag}_default_cmd_summary.md"), "w").write("\n".join(lines) + "\n")
+open(os.path.join(out, f"{tag}_default_cmd_summary.md"), "w")  # gpurun merges gpurun_out/ back: copy it to profiles/ from there.write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
