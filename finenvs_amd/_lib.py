@@ -49,6 +49,7 @@ SIGNATURES = {
     "fe_env_render": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "fe_env_step_notify": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "fe_env_step_traj_notify": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
+    "fe_env_step_promoted": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.c_uint64, _vp]),
     "fe_host_flag_create": (C.c_int, [C.POINTER(_vp)]),
     "fe_host_flag_destroy": (C.c_int, [_vp]),
     "fe_env_render_n": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp]),

@@ -103,7 +103,7 @@ struct Params {
     float *run_ret;      // optional episode statistics (fe_env_bind_stats): running return per env
     double *stat_acc;    // (N, 3) per-env partials: [3n] finished training episodes of env n, [3n + 1] sum of their returns, [3n + 2] sum of squares
     float *stat_eval;    // [0] return of the eval env's last finished episode, [1] how many it finished
-    const float *actions;
+    const float *actions;  // f32 actions; PROMO launches with act_f64 read them as const double * instead
     void *obs;
     double *rew;
     int32_t *done;
@@ -125,6 +125,10 @@ struct Params {
     FastDiv div_A;
     float scale32, ms32, c32, imr32, S32;
     double comm, imr, one_mmr, S;
+    // PROMO launches only (fe_env_step_promoted), kept at the END of the block: the other kernels' scalar loads of the
+    // fields above stay as they were
+    double scale64, ms64;  // max_shares + 0.5 and max_shares in f64 (f64 actions)
+    int32_t act_f64;       // this step's actions are f64 (TSE:298-302 in f64)
 };
 
 // ---- Philox4x32-10, the redraw generator of redraw_mode 1 ----
@@ -171,24 +175,54 @@ struct Sleeve {
 
 // One (env, asset) account for one bar: TSE:298-421 (trade), TSE:428-431
 // (position feature), TSE:447-475 (reward).  Pure register arithmetic.
-__device__ __forceinline__ void sleeve_step(const Params &p, float action, double O, double H, double Lo,
-                                            double C, Sleeve &s) {
+// PROMO = the arithmetic of an env whose share tensors have been PROMOTED to f64 (fe_env_step_promoted): the reference's
+// long_shares / short_shares are f32 until the first step() with f64 actions rebinds them to f64 results (TSE:353-361,
+// 367-374) and stay f64 from then on.  Share counts are small integers -- the same values in either dtype -- so what
+// changes is the precision of three kinds of products: shares x per_share_commission is an f64 product added once-
+// rounded into the f32 commission accumulator (TSE:363-365) for the sell / buy-back legs always, and for the entry legs
+// when this step's share CHANGES are f64 too (f64 actions; with f32 actions they are f32 tensors and stay f32 products);
+// the short-entry commission likewise (TSE:401-421); and the share change itself is scaled, rounded and clamped in
+// the actions' dtype (TSE:298-302).  The liquidation fee follows in account_core.
+template <bool PROMO>
+__device__ __forceinline__ void sleeve_step(const Params &p, typename std::conditional<PROMO, double, float>::type action,
+                                            double O, double H, double Lo, double C, Sleeve &s) {
     float cash = s.cash, lng = s.lng, sht = s.sht;
     double margin = s.margin;
     float comm = 0.0f;  // TSE:305
+    const bool a64 = PROMO && p.act_f64 != 0;  // this step's share changes are f64 (uniform)
 
     // TSE:298-302  round-half-even then clamp
-    float sc = rintf(action * p.scale32);
-    sc = sc < -p.ms32 ? -p.ms32 : sc;
-    sc = sc > p.ms32 ? p.ms32 : sc;
+    float sc;
+    if constexpr (PROMO) {
+        if (a64) {
+            double s64 = rint(action * p.scale64);
+            s64 = s64 < -p.ms64 ? -p.ms64 : s64;
+            s64 = s64 > p.ms64 ? p.ms64 : s64;
+            sc = (float)s64;  // an integer in [-max_shares, max_shares] (or NaN): exact
+        } else {
+            sc = rintf((float)action * p.scale32);  // (an f32 action, carried as a double)
+            sc = sc < -p.ms32 ? -p.ms32 : sc;
+            sc = sc > p.ms32 ? p.ms32 : sc;
+        }
+    } else {
+        sc = rintf(action * p.scale32);
+        sc = sc < -p.ms32 ? -p.ms32 : sc;
+        sc = sc > p.ms32 ? p.ms32 : sc;
+    }
     float pos = sc < 0.0f ? 0.0f : sc;  // TSE:344-351
     float neg = sc > 0.0f ? 0.0f : sc;
+    // commissions += num_shares * per_share_commission, TSE:363-365: an f32 product and an f32 sum, or -- `wide`: the
+    // share count is an f64 tensor -- an f64 product added to the f32 accumulator with ONE rounding
+    auto add_commission = [&](float shares, bool wide) {
+        if (wide) comm = (float)((double)comm + (double)shares * p.comm);
+        else comm += shares * p.c32;
+    };
 
     // sell long positions first, TSE:353-361
     float nl = relu32(lng + neg);
     float sell = lng - nl;
     neg += sell;
-    comm += sell * p.c32;
+    add_commission(sell, PROMO);
     cash = (float)((double)cash + (double)sell * (O - p.comm));
     lng = nl;
 
@@ -196,7 +230,7 @@ __device__ __forceinline__ void sleeve_step(const Params &p, float action, doubl
     float ns = relu32(sht - pos);
     float bb = sht - ns;
     pos -= bb;
-    comm += bb * p.c32;
+    add_commission(bb, PROMO);
     cash = (float)((double)cash - (double)bb * (O + p.comm));
     sht = ns;
     double nm = (double)(p.imr32 * sht) * O;
@@ -205,19 +239,20 @@ __device__ __forceinline__ void sleeve_step(const Params &p, float action, doubl
 
     // long entry unless unaffordable, TSE:385-399
     if ((double)cash - (double)pos * (O + p.comm) < 0.0) pos = 0.0f;
-    comm += pos * p.c32;
+    add_commission(pos, a64);
     cash = (float)((double)cash - (double)pos * (O + p.comm));
     lng += pos;
 
     // short entry unless the 150% margin is unaffordable, TSE:401-421
     float q = -neg;
-    if (((double)cash - p.imr * ((double)q * O)) - (double)(q * p.c32) < 0.0) {
+    // short_commission = -negative_share_changes * per_share_commission: in the share changes' dtype
+    if (((double)cash - p.imr * ((double)q * O)) - (a64 ? (double)q * p.comm : (double)(q * p.c32)) < 0.0) {
         neg = 0.0f;
         q = -neg;
     }
-    comm += q * p.c32;
+    add_commission(q, a64);
     double req = p.imr * ((double)q * O);
-    cash = (float)((double)cash - (req + (double)(q * p.c32)));
+    cash = (float)((double)cash - (req + (a64 ? (double)q * p.comm : (double)(q * p.c32))));
     margin += req;
     sht += q;
 

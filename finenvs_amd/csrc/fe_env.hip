@@ -180,14 +180,24 @@ static const void *kernel_for(bool f32, int vec, bool single) {
 #undef FE_PICK
 }
 
+// fe_env_step_promoted: the multi-asset tile loop (any A) with the promoted arithmetic, full forms only.
+template <int FORM>
+static const void *promoted_kernel_for(bool f32, int vec) {
+#define FE_PICK(OT, VEC) ((const void *)fe_env_promoted_kernel<OT, VEC, FORM>)
+    if (f32) return vec == 4 ? FE_PICK(float, 4) : (vec == 2 ? FE_PICK(float, 2) : FE_PICK(float, 1));
+    return vec == 2 ? FE_PICK(double, 2) : FE_PICK(double, 1);
+#undef FE_PICK
+}
+
 // Per-call pointers go into a local copy of the parameter block: the env object itself is not
 // modified by reset/step, so concurrent calls on different streams do not race on the host side.
 template <bool RESET_ONLY>
 static int launch_env(const fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
                       hipStream_t st, int64_t *desc_src = nullptr, double *desc_pos = nullptr, float *act_store = nullptr,
-                      uint64_t *host_flag = nullptr, uint64_t flag_seq = 0) {
+                      uint64_t *host_flag = nullptr, uint64_t flag_seq = 0, int promoted = -1) {
     Params p = env->p;
     p.actions = actions;
+    p.act_f64 = promoted == 1 ? 1 : 0;
     p.obs = obs;
     p.rew = rewards;
     p.done = dones;
@@ -204,7 +214,14 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     const void *kern = RESET_ONLY ? kernel_for<true, kLean>(f32, env->vec, single)
                        : (host_flag ? (full ? kernel_for<false, kFullNotify>(f32, env->vec, single) : kernel_for<false, kNotify>(f32, env->vec, single))
                                     : (full ? kernel_for<false, kFull>(f32, env->vec, single) : kernel_for<false, kLean>(f32, env->vec, single)));
-    hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, env->lds, st);
+    size_t lds = env->lds;
+    if (!RESET_ONLY && promoted >= 0) {
+        // the multi-asset tile loop for any A: its per-sleeve LDS arrays exist for A = 1 too (lds_bytes leaves them out there)
+        kern = host_flag ? promoted_kernel_for<kFullNotify>(f32, env->vec) : promoted_kernel_for<kFull>(f32, env->vec);
+        const size_t S = (size_t)p.EB * p.A;
+        lds = (4 * (size_t)kStageBytes + (size_t)p.EB * 8 + S * 8 + S * 8 + S * 4 + S * 4 + (size_t)p.EB * 4 + 15) & ~(size_t)15;
+    }
+    hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");
     return FE_OK;
 }
@@ -396,6 +413,8 @@ int fe_env_create(const fe_config *cfg, const double *prices, const double *logr
     p.div_WA = make_fastdiv((uint32_t)((int64_t)cfg->W * cfg->A));
     p.div_A = make_fastdiv((uint32_t)A);
     p.scale32 = (float)((double)cfg->max_shares + 0.5);
+    p.scale64 = (double)cfg->max_shares + 0.5;
+    p.ms64 = (double)cfg->max_shares;
     p.ms32 = (float)cfg->max_shares;
     p.c32 = (float)cfg->commission;
     p.imr32 = (float)cfg->init_margin;
@@ -487,6 +506,23 @@ int fe_env_step_traj_notify(fe_env *env, const float *actions, void *obs, double
         return fail(FE_ERR_ARG, "fe_env_step_notify: this training-mode env has no evaluation env (a shard that does not own it)");
     return launch_env<false>(env, actions, obs, rewards, dones, (hipStream_t)stream, obs_src_out, obs_pos_out, actions_store_out,
                              host_flag, seq);
+}
+
+int fe_env_step_promoted(fe_env *env, const void *actions, int32_t actions_are_f64, void *obs, double *rewards,
+                         int32_t *dones, float *actions_store_out, int64_t *obs_src_out, double *obs_pos_out,
+                         uint64_t *host_flag, uint64_t seq, void *stream) {
+    if (!env || !actions || !obs || !rewards || !dones) return fail(FE_ERR_ARG, "fe_env_step_promoted: null argument");
+    if (actions_are_f64 != 0 && actions_are_f64 != 1) return fail(FE_ERR_ARG, "fe_env_step_promoted: actions_are_f64 must be 0 or 1");
+    if ((obs_src_out == nullptr) != (obs_pos_out == nullptr))
+        return fail(FE_ERR_ARG, "fe_env_step_promoted: obs_src_out and obs_pos_out go together");
+    if (actions_store_out && actions_are_f64)
+        return fail(FE_ERR_ARG, "fe_env_step_promoted: actions_store_out is an f32 copy; f64 actions have none");
+    if (actions_store_out == actions) actions_store_out = nullptr;
+    if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step_promoted: state not bound");
+    if (host_flag && env->p.eval_env < 0 && !env->cfg.evaluate)
+        return fail(FE_ERR_ARG, "fe_env_step_promoted: this training-mode env has no evaluation env (a shard that does not own it)");
+    return launch_env<false>(env, reinterpret_cast<const float *>(actions), obs, rewards, dones, (hipStream_t)stream, obs_src_out,
+                             obs_pos_out, actions_store_out, host_flag, seq, actions_are_f64);
 }
 
 int fe_host_flag_create(uint64_t **host_flag) {

@@ -41,7 +41,7 @@ __device__ __forceinline__ void account_keep(const Params &p, const TileLds &l, 
         s.lng = st.lng;
         s.sht = st.sht;
         s.margin = st.margin;
-        sleeve_step(p, action, bar.x, bar.y, bar.z, bar.w, s);
+        sleeve_step<false>(p, action, bar.x, bar.y, bar.z, bar.w, s);
         sdone = s.bankrupt | (nxt >= L) | (probe != probe);
         l.pos[e * A + a] = s.pos_obs;
         st.obs_pos = s.pos_obs;

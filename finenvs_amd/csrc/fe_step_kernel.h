@@ -15,9 +15,12 @@ namespace {
 constexpr int kLean = 0, kFull = 1, kNotify = 2, kFullNotify = 3;
 constexpr bool form_is_full(int form) { return form == kFull || form == kFullNotify; }
 constexpr bool form_notifies(int form) { return form == kNotify || form == kFullNotify; }
-template <bool SINGLE, int FORM>
+// PROMO: the arithmetic of an env whose share tensors the reference has promoted to f64 (sleeve_step, fe_device_common.h).
+template <bool PROMO>
+using ActionT = typename std::conditional<PROMO, double, float>::type;
+template <bool SINGLE, int FORM, bool PROMO = false>
 __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, int A, int e, int a, bool active,
-                                             int64_t n, int64_t sl, const SleeveIn &in, float action,
+                                             int64_t n, int64_t sl, const SleeveIn &in, ActionT<PROMO> action,
                                              double *rew_out, int32_t *done_out) {
     const int64_t rs = 4 * (int64_t)A;
     const int W = p.W;
@@ -32,7 +35,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
         s.lng = in.lng;
         s.sht = in.sht;
         s.margin = in.margin;
-        sleeve_step(p, action, in.bar.x, in.bar.y, in.bar.z, in.bar.w, s);
+        sleeve_step<PROMO>(p, action, in.bar.x, in.bar.y, in.bar.z, in.bar.w, s);
         // termination: bankrupt | end of buffer | next open log-return is NaN, TSE:477-496
         sdone = s.bankrupt | (in.nxt >= L) | (in.probe != in.probe);
         l.pos[e * A + a] = s.pos_obs;
@@ -51,7 +54,7 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
                 p.desc_pos[sl] = s.pos_obs;
                 if (a == 0) p.desc_src[n] = l.src[e];
             }
-            if (p.act_store) p.act_store[sl] = action;  // agent.store's `actions` field, no copy kernel
+            if (p.act_store) p.act_store[sl] = (float)action;  // agent.store's `actions` field, no copy kernel (f32 actions only)
         }
     }
     // ---------------- phase 1b: one lane per env ----------------
@@ -67,8 +70,13 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             for (int k = 0; k < A; ++k) any |= l.flg[e * A + k] != 0;
             rew = 0.0;
             for (int k = 0; k < A; ++k) {  // sleeve contract: sum in asset order
-                float fee = ((any ? 1.0f : 0.0f) * l.shr[e * A + k]) * p.c32;
-                double r = l.rew[e * A + k] - (double)fee;
+                double r;
+                if constexpr (PROMO) {  // num_shares is an f64 tensor: dones * num_shares * commission in f64, TSE:288-289
+                    r = l.rew[e * A + k] - ((any ? 1.0 : 0.0) * (double)l.shr[e * A + k]) * p.comm;
+                } else {
+                    float fee = ((any ? 1.0f : 0.0f) * l.shr[e * A + k]) * p.c32;
+                    r = l.rew[e * A + k] - (double)fee;
+                }
                 rew = (k == 0) ? r : rew + r;
             }
             l.any[e] = any ? 1 : 0;
@@ -138,15 +146,15 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
 }
 
 // unpipelined form: load, then account
-template <bool SINGLE, int FORM>
+template <bool SINGLE, int FORM, bool PROMO = false>
 __device__ __forceinline__ void account_tile(const Params &p, const TileLds &l, int A, int e, int a, bool active,
-                                             int64_t n, int64_t sl, float action, double *rew_out,
+                                             int64_t n, int64_t sl, ActionT<PROMO> action, double *rew_out,
                                              int32_t *done_out) {
     int64_t idx, spot;
     SleeveIn in;
     load_head(p, active, n, idx, spot);
     load_body(p, A, a, active, sl, idx, spot, in);
-    account_core<SINGLE, FORM>(p, l, A, e, a, active, n, sl, in, action, rew_out, done_out);
+    account_core<SINGLE, FORM, PROMO>(p, l, A, e, a, active, n, sl, in, action, rew_out, done_out);
 }
 
 // reset(): the observation descriptors of the CURRENT state (TSE:423-435); changes no state.
@@ -394,8 +402,11 @@ template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY>
 constexpr int kEnvKernelWaves = !SINGLE ? kMultiAssetWaves
                                 : (RESET_ONLY ? kRenderWaves
                                               : (sizeof(OT) == 8 ? (kHoistFirst<OT> ? 4 : kRenderWaves) : kF32StepWaves<OT, VEC>));
-template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY, int FORM>
-__global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONLY>)) void fe_env_kernel(const Params p) {
+// The body of fe_env_kernel (and of fe_env_promoted_kernel: PROMO, always with SINGLE = false -- the unpipelined tile loop
+// serves A = 1 as well; the promoted arithmetic is a compatibility path, not the headline: see sleeve_step).
+template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY, int FORM, bool PROMO>
+__device__ __forceinline__ void env_kernel_body(const Params &p) {
+    static_assert(!PROMO || (!SINGLE && !RESET_ONLY && form_is_full(FORM)), "promoted arithmetic: multi-asset tile loop, full forms");
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
@@ -426,7 +437,13 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
             const bool active = e < ebt;
             const int64_t n = n0 + e;
             const int64_t sl = n * A + a;
-            account_tile<SINGLE, FORM>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
+            if constexpr (PROMO) {
+                double act = 0.0;
+                if (active) act = p.act_f64 ? reinterpret_cast<const double *>(p.actions)[sl] : (double)p.actions[sl];
+                account_tile<SINGLE, FORM, true>(p, l, A, e, a, active, n, sl, act, p.rew, p.done);
+            } else {
+                account_tile<SINGLE, FORM>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
+            }
             stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
                                          reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
             lds_barrier();  // LDS is reused by the next tile
@@ -501,6 +518,17 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
             }
         }
     }
+}
+
+template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY, int FORM>
+__global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONLY>)) void fe_env_kernel(const Params p) {
+    env_kernel_body<OT, VEC, SINGLE, RESET_ONLY, FORM, false>(p);
+}
+
+// fe_env_step_promoted: the multi-asset tile loop (any A) with the promoted arithmetic; FORM kFull or kFullNotify
+template <typename OT, int VEC, int FORM>
+__global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, false, false>)) void fe_env_promoted_kernel(const Params p) {
+    env_kernel_body<OT, VEC, false, false, FORM, true>(p);
 }
 
 }  // namespace

@@ -13,7 +13,8 @@ current stream.  There is no CPU path.
 Keyword-only extensions: ``num_envs`` (env n -> day n mod D), ``num_assets`` /
 ``prices`` / ``day_id`` (tensor input, multi-asset "sleeve" contract of
 DESIGN.md), ``tables`` (ready-made (D,L,4A) price/log-return tables),
-``obs_dtype``, ``cast_actions`` (accept non-f32 actions by casting; default: ValueError), ``obs_buffers`` (opt-in ring of env-owned observation buffers), ``obs_audition`` (ring mode:
+``obs_dtype``, ``cast_actions`` (cast non-f32 actions to f32; default: float64 actions take the reference's f64
+promotion of its share tensors, other dtypes raise ValueError), ``obs_buffers`` (opt-in ring of env-owned observation buffers), ``obs_audition`` (ring mode:
 extra candidate buffers to try at construction -- within a quarter of the free memory --, the fastest stay), ``redraw``, ``seed``, ``env_indices``, ``rank`` /
 ``world_size`` (contiguous env shards, one process per GPU).
 """
@@ -310,6 +311,9 @@ class TimeSeriesEnv:
         # redraw="torch" with an evaluation env: the per-step host read of its done flag (TSE:510) goes through a
         # coherent host flag the kernel writes as soon as that env is accounted (fe_env_step_notify), not through a
         # device-to-host copy after the launch
+        # the reference's share tensors become f64 at the first step() with float64 actions and stay f64 (step()): from then
+        # on every step goes through fe_env_step_promoted
+        self.shares_promoted = False
         self._flag = None
         self._flag_seq = 0
         self.flag_timeout_s = 60.0  # how long step() waits for the kernel's word before it synchronises and gives up
@@ -540,15 +544,21 @@ class TimeSeriesEnv:
         ``actions_out`` (N, A) f32 receives a copy of the actions -- ``agent.store``'s action field written by the kernel
         that reads the actions anyway, so the policy's output can stay where the policy wrote it."""
         N, A = self.num_envs, self.num_assets
+        act_f64 = False
         if actions.dtype is not torch.float32:
-            # With f64 actions the reference silently promotes its share counts and commission products to f64
-            # (TSE:298-302, 353-361) -- different bits from the f32 arithmetic every in-repo caller gets
-            # (PPO_agent.py:101-108 samples f32).  This build computes the f32 path only, so it says so instead of
-            # quietly answering a different question; cast_actions=True opts into the cast.
-            if not self.cast_actions:
-                raise ValueError(f"actions must be float32, got {actions.dtype} (the reference would promote its share "
-                                 "counts to that dtype; construct the env with cast_actions=True to have them cast to float32)")
-            actions = actions.float()
+            if self.cast_actions:
+                actions = actions.float()
+            elif actions.dtype is torch.float64:
+                # What the reference does with float64 actions (TSE:298-302, 353-374): the share change is computed in f64
+                # and long_shares / short_shares are REBOUND to f64 tensors -- for the life of the env, also under later
+                # f32 actions -- which makes its commission products and the liquidation fee f64 products
+                # (fe_env_step_promoted; pinned by rollout_f64_actions.npz).  This env keeps its share tensors f32 (the
+                # counts are small integers: same values) and remembers the promotion.
+                act_f64 = True
+                self.shares_promoted = True
+            else:
+                raise ValueError(f"actions must be float32 or float64, got {actions.dtype} (the reference would compute its "
+                                 "share counts in that dtype; construct the env with cast_actions=True to have them cast to float32)")
         if actions.numel() != N * A or actions.device != self._dev:
             raise ValueError(f"actions must hold {N}x{A} values on {self.device}, got {tuple(actions.shape)} on {actions.device}")
         if not actions.is_contiguous():
@@ -577,7 +587,24 @@ class TimeSeriesEnv:
                                "finenvs_amd.rollout.GraphedRollout (which defers the evaluate-mode read)")
         if notify:
             self._flag_seq = seq = (self._flag_seq + 1) & (0x7FFFFFFF if self.evaluate else 0x3FFFFFFFFFFFFFFF)
-        if descriptors_out is None and actions_out is None:
+        if self.shares_promoted:
+            src = pos = None
+            if descriptors_out is not None:
+                src, pos = descriptors_out
+                for t, count, dt in ((src, N, torch.int64), (pos, N * A, torch.float64)):
+                    if t.dtype is not dt or t.numel() != count or not t.is_contiguous() or t.device != self._dev:
+                        raise ValueError("descriptors_out must be contiguous (int64 (N,), float64 (N, A)) tensors on the env's device")
+            if actions_out is not None:
+                if act_f64:
+                    raise ValueError("actions_out is a float32 copy of the actions: not available with float64 actions")
+                if (actions_out.dtype is not torch.float32 or actions_out.numel() != N * A or not actions_out.is_contiguous()
+                        or actions_out.device != self._dev):
+                    raise ValueError("actions_out must be a contiguous float32 tensor of num_envs x num_assets elements on the env's device")
+            rc = self._lib.fe_env_step_promoted(self._handle_v, actions.data_ptr(), int(act_f64), obs.data_ptr(), rewards.data_ptr(),
+                                                dones.data_ptr(), actions_out.data_ptr() if actions_out is not None else None,
+                                                src.data_ptr() if src is not None else None, pos.data_ptr() if pos is not None else None,
+                                                self._flag if notify else None, seq if notify else 0, self._stream())
+        elif descriptors_out is None and actions_out is None:
             if notify:
                 rc = self._lib.fe_env_step_notify(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
                                                   dones.data_ptr(), self._flag, seq, self._stream())

@@ -226,6 +226,9 @@ class _FusedEvaluation:
         from the env's shared arrays.  If anything else advanced the env since this object last looked -- ``env.step``,
         another rollout object's ``run`` -- the two no longer belong together and the policy would act on a stale
         observation while the accounting uses the current state: refuse instead of running on silently."""
+        if getattr(self.env, "shares_promoted", False):
+            raise RuntimeError("this env was stepped with float64 actions: the reference computes its commissions in f64 from then on "
+                               "(fe_env_step_promoted); the fused rollouts run the f32 arithmetic only")
         if getattr(self, "_seen_generation", None) != self.env._generation:
             raise RuntimeError("the env was stepped by someone else since this rollout object's last run(): its observation "
                                "descriptors are stale.  Call sync_from_env() (= look at the state as env.reset() renders it) "

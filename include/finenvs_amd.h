@@ -143,6 +143,25 @@ int fe_env_step_notify(fe_env *env, const float *actions, void *obs, double *rew
 int fe_env_step_traj_notify(fe_env *env, const float *actions, void *obs, double *rewards, int32_t *dones,
                             float *actions_store_out, int64_t *obs_src_out, double *obs_pos_out, uint64_t *host_flag,
                             uint64_t seq, void *stream);
+/*
+ * step() of an env whose share tensors the reference has PROMOTED to f64.  TimeSeriesEnv keeps long_shares / short_shares
+ * as f32 tensors only until the first step() with float64 actions: sell_long_positions / buy_back_short_positions rebind
+ * them to f64 results (TSE:353-361, 367-374), and they stay f64 for the life of the env -- also under later f32 actions.
+ * Share counts are small integers, identical in either dtype; what changes is the precision of the products they enter:
+ *   shares * per_share_commission is an f64 product added with one rounding into the f32 commission accumulator
+ *   (TSE:363-365) -- for the sell / buy-back legs always, for the entry legs when this step's share CHANGES are f64
+ *   (actions_are_f64 = 1; with f32 actions they remain f32 products);  the short-entry commission likewise (TSE:401-421);
+ *   the share change is scaled, rounded and clamped in the actions' dtype (TSE:298-302);  the liquidation fee
+ *   dones * num_shares * per_share_commission is an f64 product (TSE:288-289).
+ * The caller owns the "has been promoted" bit (the Python class sets it at the first f64 step and routes every later step
+ * here); the state arrays stay f32 / f64 as bound (same values).  actions: (N*A) f64 if actions_are_f64 else f32.
+ * Optional outputs as fe_env_step_traj (actions_store_out only with f32 actions); host_flag / seq as fe_env_step_notify
+ * (NULL: no flag).  Runs the unpipelined tile loop for every A: a compatibility path, not the fast one.
+ */
+int fe_env_step_promoted(fe_env *env, const void *actions, int32_t actions_are_f64, void *obs, double *rewards,
+                         int32_t *dones, float *actions_store_out, int64_t *obs_src_out, double *obs_pos_out,
+                         uint64_t *host_flag, uint64_t seq, void *stream);
+
 /* A host-resident, device-visible, coherent 8-byte flag for fe_env_step_notify (TSE:510 is the host read it serves); zeroed. */
 int fe_host_flag_create(uint64_t **host_flag);
 int fe_host_flag_destroy(uint64_t *host_flag);

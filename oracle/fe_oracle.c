@@ -142,9 +142,28 @@ typedef struct sleeve_out {
     int bankrupt;    /* cash < 0 anywhere in the reward step */
 } sleeve_out;
 
-/* one (env, asset) account: steps 1-6 of SURVEY Appendix A */
-static inline void sleeve_step(const fo_config *c, float action, const double bar[4], float *cash_io,
-                               float *long_io, float *short_io, double *margin_io, sleeve_out *out) {
+/* a3 with float64 actions: the same three operations in f64 (TSE:298-302); the result is an integer in
+ * [-max_shares, max_shares] (or NaN), exact as a float */
+static inline float share_change64(const fo_config *c, double action) {
+    double scaled = action * ((double)c->max_shares + 0.5);
+    double sc = rint(scaled);
+    double ms = (double)c->max_shares;
+    if (sc < -ms) sc = -ms;
+    if (sc > ms) sc = ms;
+    return (float)sc;
+}
+
+/* one (env, asset) account: steps 1-6 of SURVEY Appendix A.
+ * sh64 / a64: the dtype promotion the reference goes through once step() has been given float64 actions.  Its
+ * long_shares / short_shares tensors start as f32 (TSE:246-251) and are REBOUND to the results of expressions that involve
+ * the share changes (TSE:353-361, 367-374): f64 from the first f64-action step on, for the life of the env (sh64).  Share
+ * counts are small integers -- identical values in either dtype, kept as floats here -- so only products change:
+ *   num_shares * per_share_commission (TSE:363-365) is an f64 product, added into the f32 `commissions` tensor in place
+ *   (one rounding of the exact f64 sum), when num_shares is f64: the sold / bought-back counts under sh64, the entry
+ *   counts only when THIS step's share changes are f64 (a64: f64 actions; f32 actions give f32 share-change tensors);
+ *   short_commission (TSE:401-421) is in the share changes' dtype as well. */
+static inline void sleeve_step(const fo_config *c, float action, double action64, int a64, int sh64, const double bar[4],
+                               float *cash_io, float *long_io, float *short_io, double *margin_io, sleeve_out *out) {
     const double O = bar[0], H = bar[1], Lo = bar[2], C = bar[3];
     const double comm_d = c->commission;
     const float c32 = (float)c->commission;
@@ -155,7 +174,9 @@ static inline void sleeve_step(const fo_config *c, float action, const double ba
     double margin = *margin_io;
     float comm = 0.0f; /* TSE:305 */
 
-    float sc = share_change(c, action);
+#define FO_ADD_COMMISSION(shares, wide) \
+    do { if (wide) comm = (float)((double)comm + (double)(shares) * comm_d); else comm += (shares) * c32; } while (0)
+    float sc = a64 ? share_change64(c, action64) : share_change(c, action);
     float pos = sc < 0.0f ? 0.0f : sc; /* TSE:344-351 */
     float neg = sc > 0.0f ? 0.0f : sc;
 
@@ -163,7 +184,7 @@ static inline void sleeve_step(const fo_config *c, float action, const double ba
     float nl = relu32(lng + neg);
     float sell = lng - nl;
     neg += sell;
-    comm += sell * c32;
+    FO_ADD_COMMISSION(sell, sh64);
     cash = (float)((double)cash + (double)sell * (O - comm_d));
     lng = nl;
 
@@ -171,7 +192,7 @@ static inline void sleeve_step(const fo_config *c, float action, const double ba
     float ns = relu32(sht - pos);
     float bb = sht - ns;
     pos -= bb;
-    comm += bb * c32;
+    FO_ADD_COMMISSION(bb, sh64);
     cash = (float)((double)cash - (double)bb * (O + comm_d));
     sht = ns;
     double nm = (double)(imr32 * sht) * O;
@@ -180,19 +201,20 @@ static inline void sleeve_step(const fo_config *c, float action, const double ba
 
     /* 3 long entry, TSE:385-399 */
     if ((double)cash - (double)pos * (O + comm_d) < 0.0) pos = 0.0f;
-    comm += pos * c32;
+    FO_ADD_COMMISSION(pos, a64);
     cash = (float)((double)cash - (double)pos * (O + comm_d));
     lng += pos;
 
     /* 4 short entry, TSE:401-421 */
     float q = -neg;
-    if (((double)cash - imr * ((double)q * O)) - (double)(q * c32) < 0.0) {
+    if (((double)cash - imr * ((double)q * O)) - (a64 ? (double)q * comm_d : (double)(q * c32)) < 0.0) {
         neg = 0.0f;
         q = -neg;
     }
-    comm += q * c32;
+    FO_ADD_COMMISSION(q, a64);
     double req = imr * ((double)q * O);
-    cash = (float)((double)cash - (req + (double)(q * c32)));
+    cash = (float)((double)cash - (req + (a64 ? (double)q * comm_d : (double)(q * c32))));
+#undef FO_ADD_COMMISSION
     margin += req;
     sht += q;
 
@@ -241,10 +263,16 @@ static inline void sleeve_step(const fo_config *c, float action, const double ba
  * redraw_counter (1) u64 is used by redraw_mode 1 only.
  * obs is (N, W, 5A) f64 (or f32 when cfg->obs_is_f32).
  */
-int fo_step(const fo_config *c, const double *P, const double *LR, int64_t *env_idx, int64_t *spot0,
-            float *cash, float *lng, float *sht, double *margin, uint8_t *terminated,
-            float *episode_returns, int64_t *n_terminated, uint64_t *redraw_counter,
-            const float *actions, void *obs, double *rew_out, int32_t *done_out, int nthreads) {
+/* fo_step_ex: `actions` is (N*A) f64 when act_f64 else f32; shares_f64: the env's share tensors have been promoted to f64
+ * (see sleeve_step; act_f64 implies it).  fo_step below = the all-f32 case every in-repo caller of the reference runs. */
+int fo_step_ex(const fo_config *c, const double *P, const double *LR, int64_t *env_idx, int64_t *spot0,
+               float *cash, float *lng, float *sht, double *margin, uint8_t *terminated,
+               float *episode_returns, int64_t *n_terminated, uint64_t *redraw_counter,
+               const void *actions_any, int act_f64, int shares_f64, void *obs, double *rew_out, int32_t *done_out,
+               int nthreads) {
+    const float *actions = (const float *)actions_any;
+    const double *actions64 = (const double *)actions_any;
+    if (act_f64) shares_f64 = 1;
     const int64_t N = c->N, L = c->L;
     const int32_t W = c->W, A = c->A;
     const int64_t rs = 4 * (int64_t)A; /* table row stride in doubles */
@@ -265,8 +293,8 @@ int fo_step(const fo_config *c, const double *P, const double *LR, int64_t *env_
         int any_done = 0;
         for (int32_t a = 0; a < A; ++a) {
             sleeve_out so;
-            sleeve_step(c, actions[n * A + a], Pd + last * rs + 4 * a, &cash[n * A + a],
-                        &lng[n * A + a], &sht[n * A + a], &margin[n * A + a], &so);
+            sleeve_step(c, act_f64 ? 0.0f : actions[n * A + a], act_f64 ? actions64[n * A + a] : 0.0, act_f64, shares_f64,
+                        Pd + last * rs + 4 * a, &cash[n * A + a], &lng[n * A + a], &sht[n * A + a], &margin[n * A + a], &so);
             posv[a] = so.pos_obs;
             rewv[a] = so.rew;
             /* 7 termination, TSE:477-496 */
@@ -278,8 +306,13 @@ int fo_step(const fo_config *c, const double *P, const double *LR, int64_t *env_
         /* liquidation fee on every sleeve of a finished env, TSE:288-289 */
         double rew = 0.0;
         for (int32_t a = 0; a < A; ++a) {
-            float fee = ((any_done ? 1.0f : 0.0f) * (sht[n * A + a] + lng[n * A + a])) * c32;
-            double r = rewv[a] - (double)fee;
+            double r;
+            if (shares_f64) {  /* num_shares is an f64 tensor: dones * num_shares * per_share_commission in f64 */
+                r = rewv[a] - ((any_done ? 1.0 : 0.0) * ((double)sht[n * A + a] + (double)lng[n * A + a])) * c->commission;
+            } else {
+                float fee = ((any_done ? 1.0f : 0.0f) * (sht[n * A + a] + lng[n * A + a])) * c32;
+                r = rewv[a] - (double)fee;
+            }
             rew = (a == 0) ? r : rew + r;
         }
         /* observation: terminal window + position column, TSE:423-445 */
@@ -334,6 +367,14 @@ int fo_step(const fo_config *c, const double *P, const double *LR, int64_t *env_
         done_out[n] = any_done;
     }
     return 0;
+}
+
+int fo_step(const fo_config *c, const double *P, const double *LR, int64_t *env_idx, int64_t *spot0,
+            float *cash, float *lng, float *sht, double *margin, uint8_t *terminated,
+            float *episode_returns, int64_t *n_terminated, uint64_t *redraw_counter,
+            const float *actions, void *obs, double *rew_out, int32_t *done_out, int nthreads) {
+    return fo_step_ex(c, P, LR, env_idx, spot0, cash, lng, sht, margin, terminated, episode_returns, n_terminated,
+                      redraw_counter, actions, 0, 0, obs, rew_out, done_out, nthreads);
 }
 
 /* a10/a11: reset() only renders the observation of the current state, TSE:423-445 */

@@ -311,11 +311,18 @@ class OracleEnv:
         return self.obs
 
     def step(self, actions: np.ndarray) -> Tuple[np.ndarray, np.ndarray, np.ndarray, Dict]:
-        a = np.ascontiguousarray(actions, dtype=np.float32).reshape(self.N, self.A)
-        rc = lib().fo_step(C.byref(self.cfg), _p(self.P), _p(self.LR), _p(self.env_idx), _p(self.spot0),
-                           _p(self.cash), _p(self.long), _p(self.short), _p(self.margin), _p(self.terminated),
-                           _p(self.episode_returns), _p(self.n_terminated), _p(self.redraw_counter), _p(a),
-                           _p(self.obs), _p(self.rew), _p(self.done), C.c_int(self.nthreads))
+        """float64 actions take the reference's dtype promotion (TSE:298-302, 353-374): the share tensors are f64 from that
+        step on (``self.shares_f64``, sticky), which changes the precision of the commission products -- see fo_step_ex."""
+        actions = np.asarray(actions)
+        act_f64 = actions.dtype == np.float64
+        if act_f64:
+            self.shares_f64 = True
+        a = np.ascontiguousarray(actions, dtype=np.float64 if act_f64 else np.float32).reshape(self.N, self.A)
+        rc = lib().fo_step_ex(C.byref(self.cfg), _p(self.P), _p(self.LR), _p(self.env_idx), _p(self.spot0),
+                              _p(self.cash), _p(self.long), _p(self.short), _p(self.margin), _p(self.terminated),
+                              _p(self.episode_returns), _p(self.n_terminated), _p(self.redraw_counter), _p(a),
+                              C.c_int(int(act_f64)), C.c_int(int(getattr(self, "shares_f64", False))),
+                              _p(self.obs), _p(self.rew), _p(self.done), C.c_int(self.nthreads))
         if rc != 0:
             raise RuntimeError(f"fo_step failed: {rc}")
         info: Dict = {}

@@ -278,23 +278,46 @@ def test_two_envs_on_two_streams_do_not_interfere(fe, fo):
         assert torch.equal(last[i], alone[i][1]) and torch.equal(envs[i].cash, alone[i][2])
 
 
-def test_non_f32_actions_are_refused_unless_cast(fe, fo):
-    """With f64 actions the reference promotes its share counts and commission products to f64 (TSE:298-302,
-    353-361): different arithmetic from the f32 path this build computes.  Refused by default; cast_actions=True
-    opts into the cast and then equals the f32 call bit for bit."""
+def test_action_dtypes_cast_promote_or_refuse(fe, fo):
+    """float64 actions take the reference's dtype promotion (TSE:298-302, 353-374; pinned by rollout_f64_actions.npz in
+    tests/test_hip_parity.py) and here, for seeded multi-asset inputs, equal the oracle's promoted arithmetic bit for bit;
+    cast_actions=True opts into a cast to f32 instead (then equal to the f32 call); other dtypes are refused."""
     P, LR = _tables(fo, 5, 1, 40, 8)
     a64 = (torch.rand((12, 1), generator=torch.Generator().manual_seed(3), dtype=torch.float64) * 2 - 1).cuda()
     env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=8, num_envs=12, evaluate=True)
     with pytest.raises(ValueError, match="float32"):
-        env.step(a64)
-    with pytest.raises(ValueError, match="float32"):
         env.step(a64.half())
-    o32, r32, d32, _ = env.step(a64.float())  # the refused calls changed nothing
+    o32, r32, d32, _ = env.step(a64.float())  # the refused call changed nothing
     env2 = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=8, num_envs=12, evaluate=True, cast_actions=True)
     o, r, d, _ = env2.step(a64)
+    assert not env2.shares_promoted
     assert_bits(t2n(o), t2n(o32), "obs")
     assert_bits(t2n(r), t2n(r32), "rewards")
     assert_bits(t2n(d), t2n(d32), "dones")
+    # promoted arithmetic vs the oracle: 3 assets (sleeve sum, shared done), small balance, f64 / f32 steps mixed
+    P, LR = _tables(fo, 6, 3, 40, 8)
+    N, A = 257, 3
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=8, num_envs=N, evaluate=True, starting_balance=900)
+    ref = fo.OracleEnv(P, LR, 8, num_envs=N, evaluate=True, starting_balance=900)
+    g = torch.Generator().manual_seed(5)
+    for t in range(90):
+        a = torch.rand((N, A), generator=g, dtype=torch.float64) * 2 - 1
+        a = a if (t < 30 or t >= 60) else a.float()
+        o, r, d, _ = env.step(a.cuda())
+        o2, r2, d2, _ = ref.step(a.numpy())
+        assert_bits(t2n(o), o2, f"step {t} obs"); assert_bits(t2n(r), r2, f"step {t} rewards"); assert_bits(t2n(d), d2, f"step {t} dones")
+        assert_bits(t2n(env.cash), ref.cash, f"step {t} cash")
+    assert env.shares_promoted and ref.shares_f64
+    # the fused rollouts run the f32 arithmetic only: they refuse a promoted env
+    from finenvs_amd.rollout import FusedLinearRollout
+
+    env3 = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=8, num_envs=N, redraw="device")
+    roll = FusedLinearRollout(env3, torch.ones((8, 5), dtype=torch.float64) * 0.1, 0.0)
+    roll.run(1)
+    env3.step(torch.zeros((N, A), dtype=torch.float64, device=env3.device))
+    roll.sync_from_env()
+    with pytest.raises(RuntimeError, match="float64 actions"):
+        roll.run(1)
 
 
 @pytest.mark.parametrize("N,A,W,dt", [(1003, 1, 16, torch.float64), (4099, 1, 64, torch.float32), (77, 3, 8, torch.float64)])

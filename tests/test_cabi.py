@@ -53,7 +53,7 @@ def test_the_frozen_header_stays_frozen():
     assert ext == {"fe_policy_table", "fe_env_rollout_table", "fe_env_rollout_mlp", "fe_env_rollout_lstm",
                    "fe_lstm_split_workspace_floats", "fe_env_rollout_lstm_split", "fe_lstm_forward", "fe_lstm_activations",
                    "fe_env_set_launch"}
-    assert len(core) == 33
+    assert len(core) == 34
 
 
 def test_version_and_struct_layout(lib, tmp_path):

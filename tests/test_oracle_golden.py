@@ -5,7 +5,7 @@ import pytest
 import torch
 
 from oracle import fe_oracle as fo
-from tests.helpers import assert_bits, econ_kwargs, load_golden
+from tests.helpers import assert_bits, bits_equal, econ_kwargs, load_golden
 
 TABLE_CASES = ["tables_full.npz", "tables_ragged.npz", "tables_skip2.npz", "tables_oih.npz",
                # the reference's other two fixtures, at its default window (TSE:19) and the example's (W = 4)
@@ -297,3 +297,36 @@ def test_oracle_policy_forms_are_consistent():
         obs, _, _, _ = env.step(a_win)
         obs = obs.copy()
         row_next = idx_pre * L + spot_pre + 1
+
+
+def _replay_f64_actions(g, promoted: bool):
+    """Replays rollout_f64_actions.npz through the oracle; promoted=False forces the all-f32 arithmetic (actions cast to
+    f32), the thing every other fixture pins.  Returns the first (step, field) that differs from the reference, or None."""
+    W, N = int(g["W"]), int(g["N"])
+    env = fo.OracleEnv(g["prices"], g["logret"], W, num_envs=N, evaluate=True, **econ_kwargs(g))
+    if not np.array_equal(env.reset(), g["obs_reset"]):
+        return (-1, "obs_reset")
+    for t in range(g["actions"].shape[0]):
+        a = g["actions"][t] if (g["act_f64"][t] and promoted) else g["actions"][t].astype(np.float32)
+        obs, rew, done, _ = env.step(a)
+        for name, got, want in (("rewards", rew, g["rewards"][t]), ("dones", done, g["dones"][t]), ("cash", env.cash.reshape(-1), g["cash"][t]),
+                                ("margin", env.margin.reshape(-1), g["margin"][t]),
+                                ("long", env.long.reshape(-1).astype(np.float64), g["long"][t]),
+                                ("short", env.short.reshape(-1).astype(np.float64), g["short"][t]),
+                                ("spot0", env.spot0, g["spot0"][t]), ("obs_last_row", np.ascontiguousarray(obs[:, -1, :]), g["obs_last_row"][t])):
+            if not bits_equal(np.asarray(got), np.asarray(want).astype(np.asarray(got).dtype)):  # (any NaN == any NaN)
+                return (t, name)
+    return None
+
+
+def test_float64_actions_follow_the_references_dtype_promotion():
+    """rollout_f64_actions.npz: the reference stepped with float64 actions (steps 0-59), then float32 actions on the env
+    whose share tensors that promoted to f64 (60-99), then float64 again.  The oracle's promoted arithmetic
+    (fo_step_ex: commission products, short-entry commission and liquidation fee in f64; share change in the actions'
+    dtype) reproduces every reward, done flag, state value and observation row bit for bit -- and the plain f32
+    arithmetic does NOT (the fixture can tell the two apart), which is why the build no longer casts f64 actions."""
+    g = load_golden("rollout_f64_actions.npz")
+    assert int(g["act_f64"].sum()) == 90 and g["dones"].sum() > 100
+    assert _replay_f64_actions(g, promoted=True) is None
+    diff = _replay_f64_actions(g, promoted=False)
+    assert diff is not None and diff[1] in ("rewards", "cash"), diff
