@@ -206,6 +206,15 @@ void parse_piece(Piece &pc, bool market_hours_only) {
     }
 }
 
+// parse_piece for worker threads: an exception leaving a std::thread's function is std::terminate
+void parse_piece_noexcept(Piece &pc, bool market_hours_only) noexcept {
+    try {
+        parse_piece(pc, market_hours_only);
+    } catch (...) {  // std::bad_alloc from the vectors
+        pc.error = 4;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -225,10 +234,24 @@ int64_t fe_csv_count_lines(const char *path) {
     return lines;
 }
 
+static int64_t csv_read_impl(const char *path, int64_t capacity, int32_t market_hours_only, double *prices,
+                             int64_t *day_id, int64_t *date_key, int64_t *second_of_day);
+
 int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_only, double *prices,
                     int64_t *day_id, int64_t *date_key, int64_t *second_of_day) {
     if (!path || !prices || !day_id || !second_of_day || capacity < 0)
         return fe_set_error(FE_ERR_ARG, "fe_csv_read: bad argument");
+    try {  // nothing C++ leaves this extern "C" entry point
+        return csv_read_impl(path, capacity, market_hours_only, prices, day_id, date_key, second_of_day);
+    } catch (const std::exception &e) {
+        return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s: %s", path, e.what());
+    } catch (...) {
+        return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s: unknown C++ exception", path);
+    }
+}
+
+static int64_t csv_read_impl(const char *path, int64_t capacity, int32_t market_hours_only, double *prices,
+                             int64_t *day_id, int64_t *date_key, int64_t *second_of_day) {
     Mapped m(path);
     if (!m.ok) return fe_set_error(FE_ERR_ARG, "fe_csv_read: cannot open %s", path);
     // Parsing is independent per line: the file is cut at line boundaries into one piece per thread (>= 4 MiB each, at
@@ -256,14 +279,28 @@ int64_t fe_csv_read(const char *path, int64_t capacity, int32_t market_hours_onl
             piece[i].end = cut;
         }
     }
-    if (pieces == 1) {
-        parse_piece(piece[0], market_hours_only != 0);
-    } else {
+    // No C++ exception may cross this extern "C" boundary: a worker that runs out of memory records error 4 in its piece
+    // (parse_piece_noexcept); a thread that cannot be created (std::system_error) leaves its piece to the calling thread.
+    try {
         std::vector<std::thread> workers;
-        for (size_t i = 1; i < pieces; ++i) workers.emplace_back(parse_piece, std::ref(piece[i]), market_hours_only != 0);
-        parse_piece(piece[0], market_hours_only != 0);
+        std::vector<char> started(pieces, 0);
+        for (size_t i = 1; i < pieces; ++i) {
+            try {
+                workers.emplace_back(parse_piece_noexcept, std::ref(piece[i]), market_hours_only != 0);
+                started[i] = 1;
+            } catch (const std::exception &) {
+                break;  // no more threads: the remaining pieces are parsed here
+            }
+        }
+        parse_piece_noexcept(piece[0], market_hours_only != 0);
+        for (size_t i = 1; i < pieces; ++i)
+            if (!started[i]) parse_piece_noexcept(piece[i], market_hours_only != 0);
         for (auto &w : workers) w.join();
+    } catch (const std::exception &e) {
+        return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s: %s", path, e.what());
     }
+    for (size_t i = 0; i < pieces; ++i)
+        if (piece[i].error == 4) return fe_set_error(FE_ERR_ARG, "fe_csv_read: %s: out of memory while parsing", path);
     std::unordered_map<uint64_t, int64_t> days;  // date key -> id in order of first appearance
     int64_t rows = 0, lines_before = 0;
     bool have_prev = false;

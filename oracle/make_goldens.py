@@ -308,6 +308,72 @@ def f64_actions_case():
     save_rollout(fname, env, roll)
 
 
+class RngLog:
+    """Logs every torch.rand / torch.randint call made while active (name code, shape, low, high): the draws the reference
+    takes from torch's GLOBAL generator -- which a caller seeding that generator shares with its own sampling."""
+
+    def __enter__(self):
+        self.calls = []
+        self._rand, self._randint = torch.rand, torch.randint
+
+        def rand(*size, **kw):
+            shape = tuple(size[0]) if len(size) == 1 and isinstance(size[0], (tuple, list, torch.Size)) else tuple(size)
+            if kw.get("generator") is None:
+                self.calls.append((0, shape[0], shape[1] if len(shape) > 1 else -1, 0, 0))
+            return self._rand(*size, **kw)
+
+        def randint(*args, **kw):
+            low, high, shape = (0, args[0], args[1]) if len(args) == 2 else args[:3]
+            if kw.get("generator") is None:
+                self.calls.append((1, tuple(shape)[0], -1, int(low), int(high)))
+            return self._randint(*args, **kw)
+
+        torch.rand, torch.randint = rand, randint
+        return self
+
+    def __exit__(self, *exc):
+        torch.rand, torch.randint = self._rand, self._randint
+
+
+def rng_calls_case():
+    """Which draws the reference takes from torch's global generator, and when: at construction one torch.rand per day
+    that needs NaN padding (TSE:207-210) and one torch.randint for the evaluation env's first day (TSE:253-255); per
+    step one torch.randint exactly when the evaluation env finished (TSE:510-513).  Ragged days (bars dropped), native
+    training mode (N = D + 1).  The build's redraw="torch" mode must make the same calls in the same order -- a caller who
+    seeds the global generator then sees the same stream position after any number of steps."""
+    fname = "rng_calls.npz"
+    if not wanted(fname):
+        print("   (kept)", fname)
+        return
+    prices, day_id, minute = write_case_csv("SYN_rng", 9, 40, seed=77, drop=0.15)
+    torch.manual_seed(4242)
+    with RngLog() as log:
+        env, _ = make_env("SYN_rng", 8)
+    construct = np.asarray(log.calls, dtype=np.int64).reshape(-1, 5)
+    N = env.num_envs
+    g = torch.Generator().manual_seed(3)
+    acts, step_calls, eval_done, env_idx, rewards, dones = [], [], [], [], [], []
+    init_env_idx = env.env_indices.numpy().copy()
+    for t in range(260):
+        a = (torch.rand((N, 1), generator=g) * 2 - 1).float()
+        with RngLog() as log:
+            _, rew, done, _ = env.step(a)
+        acts.append(a.squeeze(1).numpy().copy())
+        step_calls.append(np.asarray(log.calls, dtype=np.int64).reshape(-1, 5))
+        eval_done.append(int(done[-1]))
+        env_idx.append(env.env_indices.numpy().copy())
+        rewards.append(rew.numpy().copy()); dones.append(done.numpy().copy())
+    n_calls = np.asarray([c.shape[0] for c in step_calls], dtype=np.int64)
+    assert (n_calls == np.asarray(eval_done)).all() and n_calls.sum() >= 5
+    save_npz(os.path.join(GOLD, fname), W=np.int64(8), N=np.int64(N), series_prices=prices, series_day_id=day_id,
+             construct_calls=construct, step_call_counts=n_calls,
+             step_calls=np.concatenate([c for c in step_calls if c.shape[0]], axis=0),
+             actions=np.stack(acts), eval_done=np.asarray(eval_done, dtype=np.int64), init_env_idx=init_env_idx,
+             env_idx=np.stack(env_idx), rewards=np.stack(rewards), dones=np.stack(dones),
+             call_columns=np.asarray([0, 1, 2, 3, 4], dtype=np.int64))  # (kind 0 rand / 1 randint, shape[0], shape[1] or -1, low, high)
+    print(fname, "construction calls", construct.tolist(), "step redraws", int(n_calls.sum()))
+
+
 def agent_stats_case():
     """Runs the reference's own PPOAgent.store / log_progress (PPO_agent.py:110-168) -- without its networks --
     on a reference training rollout and records what they compute: the running return per env after every
@@ -551,6 +617,8 @@ def main():
 
     # float64 actions: the reference's dtype promotion of its share tensors (missing #3 of VERDICT round 3)
     f64_actions_case()
+    # the global-generator draws of the training mode, as a call log (weak #1 (ii) of VERDICT round 3)
+    rng_calls_case()
 
     # ---------------- multi-asset sleeve contract: A reference envs side by side ----------------
     sleeves_case("rollout_sleeves3.npz", "SYN_multi", A=3, N=20, W=8, T=70, days=6, bars=40, csv_seed=31, action_seed=11, full_obs=True)
