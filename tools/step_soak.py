@@ -48,7 +48,8 @@ for case in range(cases):
     f32 = bool(rng.integers(0, 2))
     evaluate = bool(rng.integers(0, 4) == 0)
     balance = float(rng.choice([10000, 2000, 600, 150]))
-    mode = str(rng.choice(["plain", "traj", "stats", "notify", "trajnotify"])) if not evaluate else str(rng.choice(["plain", "traj"]))
+    mode = (str(rng.choice(["plain", "traj", "stats", "notify", "trajnotify", "promoted"])) if not evaluate
+            else str(rng.choice(["plain", "traj", "promoted"])))
     prices, day_id, _ = synthetic.synthetic_series(days, A, bars, int(rng.integers(0, 10**6)), drop)
     try:
         P, LR, *_ = fo.tables_from_series(prices, day_id, W)
@@ -65,6 +66,8 @@ for case in range(cases):
     ref.redraw_counter[0] = 1
     lib = env._lib
     stats = EpisodeStats(env) if mode == "stats" else None
+    ref_stats = fo.EpisodeStatsOracle(N, env._eval_env) if mode == "stats" else None
+    promote_from = int(rng.integers(0, 6)) if mode == "promoted" else None  # first step with float64 actions
     flag = None
     if mode in ("notify", "trajnotify"):
         flag = C.c_void_p()
@@ -77,6 +80,9 @@ for case in range(cases):
         a = (torch.rand((N, A), generator=g) * 2 - 1).float()
         if t % 5 == 2:
             a = torch.sign(a)
+        if mode == "promoted" and t >= promote_from and (t - promote_from) % 7 < 4:
+            # float64 actions (the reference promotes its share tensors from here on; f32 steps in between stay promoted)
+            a = (torch.rand((N, A), generator=g, dtype=torch.float64) * 2 - 1) if t % 5 != 2 else a.double()
         o_r, r_r, d_r, i_r = ref.step(a.numpy())
         ad = a.to(dev)
         if mode == "traj":
@@ -121,11 +127,18 @@ for case in range(cases):
         bits(t2n(env.short_shares), ref.short, what + " short")
         bits(t2n(env._spot0), ref.spot0, what + " spot0")
         bits(t2n(env.env_indices), ref.env_idx, what + " day indices")
+        if ref_stats is not None:
+            ref_stats.step(r_r, d_r)
+            bits(t2n(stats.running_returns), ref_stats.running, what + " running returns")
         if evaluate and mode == "plain":
             assert ("returns" in i) == ("returns" in i_r), what
             if "returns" in i:
                 bits(t2n(i["returns"]), i_r["returns"], what + " returns")
     if stats is not None:
+        got, want = stats.read(), ref_stats.read()
+        for k in ("num_training_episodes", "mean_training_return", "std_dev_training_return", "evaluation_return"):
+            same = got[k] == want[k] or (isinstance(got[k], float) and got[k] != got[k] and want[k] != want[k])
+            assert same, f"case {case}: statistics {k}: {got[k]!r} vs the oracle's {want[k]!r}"
         stats.close()
     if flag is not None:
         torch.cuda.synchronize()
