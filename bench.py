@@ -649,7 +649,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             # profiles/*_kernel_stats.csv; the timed loop (env.step with trajectory slots) launches the same one, or with
             # redraw='torch' its host-flag variant (FORM 3: same arithmetic, last tile first)
             "kernel": step_kernel_name(W, A, args.obs_f32, 1),
-            "timed_loop_kernel": step_kernel_name(W, A, args.obs_f32, 3 if (args.redraw == "torch" and env._flag is not None) else 1),
+            "timed_loop_kernel": step_kernel_name(W, A, args.obs_f32, 0 if roll is not None else  # (--graph: plain env.step, the lean form)
+                                                  (3 if (args.redraw == "torch" and env._flag is not None) else 1)),
             "kernel_ms": kern_ms,
             "kernel_ms_regime": "tight loop: back-to-back C-ABI launches, one HIP-event pair around the train (kernel + the ~1.5 us "
                                 "launch boundary); Python-paced launches of the timed loop run the same kernel 5 - 10 % longer "
