@@ -944,7 +944,7 @@ def main():
                        "timed_region": "median of R blocks of exactly `steps` steps, each between (drain + synchronize + barrier + synchronize) "
                                        "fences, MAX over ranks per block.  A block of --steps 20 at 64k envs is ~0.6 ms: the idle-GPU start of "
                                        "every block (staggered XCD wake-up), the closing fence (N > 1: one barrier, tens of microseconds) and "
-                                       "fe_env_step's Python make `ms_per_step` ~5 % longer than `roofline.kernel_ms`, the launch interval of "
+                                       "env.step's Python make `ms_per_step` ~2 - 3 % longer than `roofline.kernel_ms`, the launch interval of "
                                        "long back-to-back trains"},
             # the un-auditioned regime beside the headline: same loop, same fences, the ring as the allocator handed it out
             "as_allocated": head["as_allocated"],

@@ -26,6 +26,9 @@ __global__ __launch_bounds__(kBlock) void fe_describe_kernel(const Params p, int
     }
 }
 
+// fe_env_set_day: env_idx[env] = day, stream-ordered; the day travels as a kernel argument (no host buffer to outlive)
+__global__ void fe_set_day_kernel(int64_t *env_idx, int64_t env, int64_t day) { env_idx[env] = day; }
+
 // debug check of foreign descriptors (fe_env_check_descriptors): out[0] = how many are invalid, out[1] = the smallest
 // invalid index (initialised to count by the host)
 __global__ __launch_bounds__(kBlock) void fe_check_descriptors_kernel(const int64_t *__restrict__ obs_src, int64_t count,

@@ -940,12 +940,11 @@ int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream) {
         return fail(FE_ERR_ARG, "fe_env_set_day: env %lld / day %lld out of range", (long long)env_index, (long long)day);
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
-    hipError_t he = hipMemcpyAsync(env->p.env_idx + env_index, &day, sizeof(int64_t), hipMemcpyHostToDevice,
-                                   (hipStream_t)stream);
-    if (he != hipSuccess) return hip_fail(he, "fe_env_set_day");
-    // the source is a stack variable: make the copy complete before it goes away
-    he = hipStreamSynchronize((hipStream_t)stream);
-    if (he != hipSuccess) return hip_fail(he, "fe_env_set_day sync");
+    // a one-lane launch with the day as a kernel argument: stream-ordered behind the step that finished the episode and
+    // ahead of the next one, WITHOUT a host synchronisation (round 3 copied a stack variable and had to wait for it)
+    hipLaunchKernelGGL(fe_set_day_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, env->p.env_idx, env_index, day);
+    hipError_t he = hipGetLastError();
+    if (he != hipSuccess) return hip_fail(he, "fe_env_set_day launch");
     return FE_OK;
 }
 

@@ -252,7 +252,7 @@ int fe_env_render_n(fe_env *env, const int64_t *obs_src, const double *obs_pos, 
  */
 int fe_env_check_descriptors(fe_env *env, const int64_t *obs_src, int64_t count, int64_t *first_bad, void *stream);
 
-/* env_indices[env] = day (the host half of TSE:510-513 when redraw_mode == 0). */
+/* env_indices[env] = day (the host half of TSE:510-513 when redraw_mode == 0): a one-lane launch on `stream`, no host synchronisation. */
 int fe_env_set_day(fe_env *env, int64_t env_index, int64_t day, void *stream);
 
 /* Launch geometry chosen for this env (diagnostics / bench reporting). Host pointers. */
