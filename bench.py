@@ -339,7 +339,17 @@ class Dist:
                 "env": pick(r"NCCL_[A-Z_]+ set|RCCL_[A-Z_]+ set", 8)}
 
     def barrier(self):
-        if self.dist is not None:
+        """The fence's barrier.  Over RCCL it is a one-element all-reduce ENQUEUED behind this rank's work (stream-ordered: it
+        completes once every rank's stream has reached it); the caller's torch.cuda.synchronize() then waits for work and
+        barrier together -- one host round trip per fence instead of dist.barrier()'s own device synchronise plus ours.
+        Over gloo (CPU rehearsals) a plain host barrier."""
+        if self.dist is None:
+            return
+        if self.backend == "nccl":
+            if getattr(self, "_bar", None) is None:
+                self._bar = torch.zeros((1,), dtype=torch.int32, device=self.dev)
+            self.dist.all_reduce(self._bar)
+        else:
             self.dist.barrier()
 
     def max_over_ranks(self, x: float) -> float:
@@ -459,17 +469,26 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         return {"workload": name, "config": config, "error": err or "another rank failed to build this workload"}
 
     gather = [D.multi]  # mutable: the timed legs flip it
+    gather_due = [0]    # steps until the deferred collective of the chunk just handed over is started
 
     def one_step(i):
         if traj.full():  # checked at the START of a step: a chunk completed by a block goes out with the next block
             if gather[0]:
-                traj.all_gather_async()  # overlaps the following steps; waited for before its chunk is reused
+                # chunks are switched now; the collective itself is started two steps later, when the GPU has the new
+                # chunk's first steps queued -- starting it costs the host 20 - 30 us (TrajectoryBuffer.all_gather_async).
+                # It overlaps the following steps and is waited for before its chunk is reused / by the closing fence.
+                traj.all_gather_async(defer=True)
+                gather_due[0] = 2
             else:
                 traj.clear()
         # the "policy" hands over its output buffer (a ring of 8 pre-generated action tensors: hot, as a policy's fresh
         # output is); agent.store's fields -- actions, rewards, dones -- are written into slot t by the step kernel itself
         a, r, d = traj.next_slot()
         obs, rew, done, _ = env.step(actions[i % 8], rewards_out=r, dones_out=d, actions_out=a)
+        if gather_due[0]:
+            gather_due[0] -= 1
+            if gather_due[0] == 0:
+                traj.issue_deferred()
         return obs
 
     roll = None
@@ -486,11 +505,14 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         run_steps = lambda n: [one_step(i) for i in range(n)]  # noqa: E731
 
     def fence():
+        """drain + barrier + synchronize.  N > 1 over RCCL: the barrier is enqueued behind this rank's steps and gathers, so
+        ONE synchronize covers "my work is done" and "everybody has arrived"; over gloo the host barrier needs this rank's
+        work finished first."""
         traj.drain()  # outstanding gathers belong to the timed region
-        torch.cuda.synchronize()
-        if D.dist is not None:  # (one process: there is nobody to wait for and nothing the barrier could have queued)
-            D.barrier()
+        if D.dist is not None and D.backend != "nccl":
             torch.cuda.synchronize()
+        D.barrier()  # (one process: a no-op)
+        torch.cuda.synchronize()
 
     trace = os.environ.get("FE_BENCH_TRACE") == "1"  # stderr: where a timed block's wall time goes (host issue / drain / fence)
 
@@ -669,7 +691,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         res["multi_gpu"] = {
             "ranks_seen": D.dist.get_world_size(), "collective_backend": D.backend,
             "trajectory_slots": T, "all_gather_every_steps": T,
-            "all_gather_issue": "asynchronous, at the first step after a chunk is full; drained inside the timed block",
+            "all_gather_issue": "asynchronous; chunks switch at the first step after a chunk is full, the collective is started two steps later "
+                                "(its host cost then hides behind queued steps); drained inside the timed block",
             "packed_bytes_per_rank_per_chunk": traj._nbytes,
             "gathered_bytes_per_rank_per_chunk": traj._nbytes * world,
             "value_with_all_gather": res["repeats"]["with_all_gather"]["value_median"],
@@ -681,6 +704,22 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             "gather_only_inbound_GBps_per_gpu": traj._nbytes * (D.dist.get_world_size() - 1) / statistics.median(gather_only) / 1e9,
             "exposed_ms_per_step": res["repeats"]["with_all_gather"]["ms_per_step_median"] - res["repeats"]["no_all_gather"]["ms_per_step_median"],
             "rccl": D.rccl_report(),
+        }
+        # DESIGN.md section 7's prediction evaluated for THIS world size and workload (written in round 4, before RCCL had
+        # ever run with more than one rank here): what the gather needs from xGMI and whether a block can hide it
+        ws = D.dist.get_world_size()
+        per_step = N * (8 + 4 * A + 4)
+        inbound_chunk = traj._nbytes * (ws - 1)
+        block_ms_no = res["repeats"]["no_all_gather"]["ms_per_step_median"] * steps
+        busbw = (210.0, 300.0)  # GB/s: RCCL large-message all-gather on a fully connected 8-GPU xGMI node (assumption)
+        pred = [inbound_chunk / (b * 1e9) * 1e3 for b in (busbw[1], busbw[0])] if ws > 1 else [0.0, 0.0]
+        res["multi_gpu"]["prediction"] = {
+            "source": "DESIGN.md section 7", "inbound_bytes_per_step_per_gpu": per_step * (ws - 1),
+            "inbound_GBps_needed_per_gpu": per_step * (ws - 1) / (block_ms_no / steps * 1e-3) / 1e9 if ws > 1 else 0.0,
+            "xgmi_inbound_peak_GBps_per_gpu": 7 * 153.0, "assumed_rccl_busbw_GBps": list(busbw),
+            "predicted_gather_only_ms": pred, "block_ms_without_gather": block_ms_no,
+            "predicted_hidden_behind_the_block": bool(pred[1] <= block_ms_no),
+            "gather_hbm_share_of_block": (traj._nbytes * (ws + 1)) / max(Bh * N * steps, 1),
         }
     if with_cpu and rank == 0:
         res["cpu_baseline"] = cpu_baseline(A, W)

@@ -287,25 +287,48 @@ class TrajectoryBuffer:
             return (a, r, d) + self._typed_states(out, lead=(G,)) + (out,)
         return a, r, d, out
 
-    def all_gather_async(self, group=None) -> None:
+    def all_gather_async(self, group=None, defer: bool = False) -> None:
         """Start gathering the chunk just filled on the collective's own stream and switch to the
         other chunk, so the exchange over xGMI overlaps the next T env steps.  ``wait_gathered``
-        returns the result; a chunk is waited for automatically before it is refilled."""
-        import torch.distributed as dist
+        returns the result; a chunk is waited for automatically before it is refilled.
 
-        G = dist.get_world_size(group)
+        ``defer=True`` only switches chunks now; the collective itself is started by ``issue_deferred()`` (or by the
+        next wait / drain / gather, whichever comes first).  Starting a collective costs the HOST 20 - 30 us; a loop
+        that calls it before it has queued the next steps leaves the GPU idle for that long, so a rollout loop defers it
+        until a couple of steps of the new chunk are in the queue (bench.py: the world-1 RCCL path 1.99 -> 2.1 G env-steps/s
+        together with the stream-ordered fence)."""
+        self.issue_deferred()
         i = self._cur
-        if self._gathered[i] is None:
-            self._gathered[i] = torch.empty((G, self._nbytes), dtype=torch.uint8, device=self.device)
-        self._pending[i] = dist.all_gather_into_tensor(self._gathered[i].view(-1), self._chunks[i], group=group,
-                                                       async_op=True)
+        if not defer:
+            self._issue(i, group)
         self._cur = 1 - i
         self._wait(self._cur)  # the chunk about to be refilled must have left
         if self.t == self.T:
             self._carry_state(i, self._cur)
         self.t = 0
+        if defer:
+            self._deferred = (i, group)
+
+    def _issue(self, i: int, group) -> None:
+        import torch.distributed as dist
+
+        G = dist.get_world_size(group)
+        if self._gathered[i] is None:
+            self._gathered[i] = torch.empty((G, self._nbytes), dtype=torch.uint8, device=self.device)
+        self._pending[i] = dist.all_gather_into_tensor(self._gathered[i].view(-1), self._chunks[i], group=group,
+                                                       async_op=True)
+
+    def issue_deferred(self) -> None:
+        """Start the collective of a chunk handed over with ``all_gather_async(defer=True)`` (no-op if there is none)."""
+        d = getattr(self, "_deferred", None)
+        if d is not None:
+            self._deferred = None
+            self._issue(*d)
 
     def _wait(self, i: int) -> None:
+        d = getattr(self, "_deferred", None)
+        if d is not None and d[0] == i:
+            self.issue_deferred()
         if self._pending[i] is not None:
             self._pending[i].wait()  # stream-level wait for NCCL/RCCL; blocks the host only for gloo
             self._pending[i] = None
@@ -327,6 +350,7 @@ class TrajectoryBuffer:
         return out
 
     def drain(self) -> None:
+        self.issue_deferred()
         for i in (0, 1):
             self._wait(i)
 

@@ -74,6 +74,27 @@ def _worker(rank, world, port, q, N_TOTAL):
         ok &= float(r3[rank][0, 0]) == (lo + 1000) * 0.5
         ok &= tuple(a3.shape) == (world, T, CAP, A)
         buf.drain()
+        # the deferred form of bench.py's loop: chunks switch at once, the collective starts a couple of steps later
+        # (issue_deferred) -- or, if nobody calls that, with the next wait / drain / gather
+        _fill(buf, lo + 2000, n)
+        buf.all_gather_async(defer=True)
+        ok &= len(buf) == 0 and buf._deferred is not None and buf._pending == [None, None]
+        a_, r_, d_ = buf.next_slot()      # the new chunk is already being filled
+        a_.zero_(); r_.zero_(); d_.zero_()
+        buf.issue_deferred()
+        ok &= buf._deferred is None
+        a4, r4, d4 = buf.wait_gathered()
+        ok &= all(float(r4[rr][0, 0]) == (shard_range(N_TOTAL, rr, world)[0] + 2000) * 0.5 for rr in range(world))
+        buf.clear()
+        _fill(buf, lo + 3000, n)
+        buf.all_gather_async(defer=True)  # never issued explicitly: the wait does it
+        a5, r5, d5 = buf.wait_gathered()
+        ok &= float(r5[rank][0, 0]) == (lo + 3000) * 0.5
+        buf.clear()
+        _fill(buf, lo + 4000, n)
+        buf.all_gather_async(defer=True)  # ... and so does drain()
+        buf.drain()
+        ok &= buf._deferred is None and buf._pending == [None, None]
         # the eval env (last global env) is owned by the last rank only
         owns_eval = hi == N_TOTAL
         ok &= owns_eval == (rank == world - 1)

@@ -140,6 +140,16 @@ def test_bench_helpers_and_cli_parse_without_a_gpu():
     assert bench.auto_repeats(7, 20, 3e-5) == 7 and 5 <= bench.auto_repeats(0, 20, 3.4e-5) <= 40
     assert bench.auto_repeats(0, 20, 25e-3) == 5 and bench.auto_repeats(0, 20, 1e-6) == 40
     assert set(bench.CONFIGS) == {1, 2, 3, 4, 5} and bench.CONFIGS[2][1:] == (65536, 1, 64)
+    # roofline.kernel: the instantiation names rocprofv3 prints (VEC follows fe_env_create: 16-byte packs unless W*5*A is odd)
+    assert bench.step_kernel_name(64, 1, False, 1) == "fe_env_kernel<double, 2, true, false, 1>"
+    assert bench.step_kernel_name(128, 30, False, 1) == "fe_env_kernel<double, 2, false, false, 1>"
+    assert bench.step_kernel_name(64, 1, True, 3) == "fe_env_kernel<float, 4, true, false, 3>"
+    assert bench.step_kernel_name(7, 3, False, 0) == "fe_env_kernel<double, 1, false, false, 0>"   # 105 elements: odd
+    assert bench.step_kernel_name(7, 2, True, 0) == "fe_env_kernel<float, 2, false, false, 0>"     # 70 elements: pairs only
+    assert bench.is_step_kernel("void (anonymous namespace)::fe_env_kernel<double, 2, true, false, 1>((anonymous namespace)::Params)")
+    assert not bench.is_step_kernel("void (anonymous namespace)::fe_env_kernel<double, 2, true, true, 0>((anonymous namespace)::Params)")  # reset()
+    # the audition and the settle phase are bounded
+    assert bench.AUDITION_EXTRA <= 10 and bench.AUDITION_BUDGET <= 64 << 30 and 5.0 <= bench.SETTLE_MS <= 50.0
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "--gpus" in out.stdout and "--steps" in out.stdout and "--warmup" in out.stdout
 
