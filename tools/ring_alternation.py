@@ -14,6 +14,8 @@ import sys
 PHASES = [("A only", "A"), ("B only", "B"), ("A,B alternating", "AB"), ("A,B,C round-robin", "ABC"), ("A,A,B,B", "AABB"), ("C only", "C"),
           ("A,B alternating (again)", "AB")]
 K = 240
+if sys.argv[-1] in ('3', '4', '5'):  # multi-asset configs: launches of 3.5 - 25 ms
+    K = 24
 
 
 def digest(out):
@@ -31,7 +33,7 @@ def digest(out):
             cur.append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
     phases = [p for p in phases if len(p) == K]
     for (name, pat), d in zip(PHASES, phases[-len(PHASES):]):
-        d = d[40:]  # skip the start of the train
+        d = d[K // 6:]  # skip the start of the train
         by_pos = [d[i::len(pat)] for i in range(len(pat))]
         print(f"{name:28s} avg {sum(d) / len(d):6.2f} us   by position in the pattern: " +
               "  ".join(f"{pat[i]}={sum(v) / len(v):.2f}" for i, v in enumerate(by_pos)))
