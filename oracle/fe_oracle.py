@@ -43,7 +43,7 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        # FE_ORACLE_LIB: an instrumented build of the same source (tools/sanitize_cpu.sh)
+        # FE_ORACLE_LIB: an instrumented build of the same source (tests/soak/sanitize_cpu.sh)
         _lib = C.CDLL(os.environ.get("FE_ORACLE_LIB") or build())
         _lib.fo_redraw_day.restype = C.c_int64
         _lib.fo_redraw_day.argtypes = [C.c_uint64, C.c_uint64, C.c_int64]

@@ -1,7 +1,7 @@
 """GPU box: a longer random sweep of the LSTM rollout against the oracle loop than the test suite runs (all six hidden
 sizes, 1..30 sleeves, W 1..9, partial tiles, both modes, sampled / mean actions, trajectory output, forward()).
 
-    python tools/lstm_soak.py [cases] [seed]
+    python tests/soak/lstm_soak.py [cases] [seed]
 """
 import os
 import sys
@@ -9,7 +9,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import finenvs_amd as fe  # noqa: E402
 from finenvs_amd.rollout import FusedLSTMRollout  # noqa: E402
 from finenvs_amd.trajectory import TrajectoryBuffer  # noqa: E402

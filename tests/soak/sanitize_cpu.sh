@@ -2,7 +2,7 @@
 # CPU-only sanitizer pass (ASan + UBSan) over the host-side native code: the C oracle and the CSV reader.
 # GPU sanitizers are not available on this pool; the HIP kernels are covered by the parity suite instead.
 set -e
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 OUT=${TMPDIR:-/tmp}/fe_sanitize
 mkdir -p $OUT
 gcc -g -O1 -fsanitize=address,undefined -fno-omit-frame-pointer -ffp-contract=off -fopenmp -fPIC -shared \

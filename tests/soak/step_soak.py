@@ -2,7 +2,7 @@
 launch can be made -- plain (lean form), with trajectory outputs / episode statistics / evaluate mode (full form),
 fe_env_step_notify (notify form, last tile first).  Complements the fixed cases of tests/test_hip_parity.py.
 
-    python tools/step_soak.py [cases] [seed]
+    python tests/soak/step_soak.py [cases] [seed]
 """
 import ctypes as C
 import os
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import finenvs_amd  # noqa: E402
 from finenvs_amd import _lib  # noqa: E402
 from finenvs_amd.data import synthetic  # noqa: E402

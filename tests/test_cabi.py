@@ -114,6 +114,29 @@ def test_product_never_imports_the_oracle():
     assert not bad, bad
 
 
+def test_only_the_checkers_use_the_oracle():
+    """oracle/ is the checker: only tests/ (incl. tests/soak/), __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+    import or execute it -- not the product (above), and not tools/ or examples/ either."""
+    import ast
+
+    bad = []
+    for sub in ("tools", "examples"):
+        for root, _, files in os.walk(os.path.join(REPO, sub)):
+            for f in files:
+                if f.endswith((".py", ".sh", ".hip", ".c", ".cpp")):
+                    txt = open(os.path.join(root, f), errors="ignore").read()
+                    if re.search(r"\b(from|import)\s+oracle\b|fe_oracle\.(py|c)|libfe_oracle|import fe_oracle", txt):
+                        bad.append(os.path.join(root, f))
+    assert not bad, bad
+    # bench.py: exactly one import of the oracle, inside cpu_baseline()
+    tree = ast.parse(open(os.path.join(REPO, "bench.py")).read())
+    where = [fn.name for fn in ast.walk(tree) if isinstance(fn, ast.FunctionDef)
+             for node in ast.walk(fn) if isinstance(node, ast.ImportFrom) and node.module == "oracle"]
+    assert where == ["cpu_baseline"], where
+    top = [node for node in tree.body if isinstance(node, (ast.Import, ast.ImportFrom)) and "oracle" in ast.dump(node)]
+    assert not top
+
+
 def test_integration_doc_names_every_entry_point():
     """INTEGRATION.md must map every symbol of the header to the reference code it replaces."""
     doc = open(os.path.join(REPO, "INTEGRATION.md")).read()
