@@ -587,48 +587,34 @@ class TimeSeriesEnv:
                                "finenvs_amd.rollout.GraphedRollout (which defers the evaluate-mode read)")
         if notify:
             self._flag_seq = seq = (self._flag_seq + 1) & (0x7FFFFFFF if self.evaluate else 0x3FFFFFFFFFFFFFFF)
+        # optional trajectory outputs (validated once, whichever entry point takes them)
+        src = pos = None
+        if descriptors_out is not None:
+            src, pos = descriptors_out
+            for t, count, dt in ((src, N, torch.int64), (pos, N * A, torch.float64)):
+                if t.dtype is not dt or t.numel() != count or not t.is_contiguous() or t.device != self._dev:
+                    raise ValueError("descriptors_out must be contiguous (int64 (N,), float64 (N, A)) tensors on the env's device")
+        if actions_out is not None:
+            if act_f64:
+                raise ValueError("actions_out is a float32 copy of the actions: not available with float64 actions")
+            if (actions_out.dtype is not torch.float32 or actions_out.numel() != N * A or not actions_out.is_contiguous()
+                    or actions_out.device != self._dev):
+                raise ValueError("actions_out must be a contiguous float32 tensor of num_envs x num_assets elements on the env's device")
+        outs = (actions_out.data_ptr() if actions_out is not None else None, src.data_ptr() if src is not None else None,
+                pos.data_ptr() if pos is not None else None)
+        base = (self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr())
         if self.shares_promoted:
-            src = pos = None
-            if descriptors_out is not None:
-                src, pos = descriptors_out
-                for t, count, dt in ((src, N, torch.int64), (pos, N * A, torch.float64)):
-                    if t.dtype is not dt or t.numel() != count or not t.is_contiguous() or t.device != self._dev:
-                        raise ValueError("descriptors_out must be contiguous (int64 (N,), float64 (N, A)) tensors on the env's device")
-            if actions_out is not None:
-                if act_f64:
-                    raise ValueError("actions_out is a float32 copy of the actions: not available with float64 actions")
-                if (actions_out.dtype is not torch.float32 or actions_out.numel() != N * A or not actions_out.is_contiguous()
-                        or actions_out.device != self._dev):
-                    raise ValueError("actions_out must be a contiguous float32 tensor of num_envs x num_assets elements on the env's device")
-            rc = self._lib.fe_env_step_promoted(self._handle_v, actions.data_ptr(), int(act_f64), obs.data_ptr(), rewards.data_ptr(),
-                                                dones.data_ptr(), actions_out.data_ptr() if actions_out is not None else None,
-                                                src.data_ptr() if src is not None else None, pos.data_ptr() if pos is not None else None,
+            rc = self._lib.fe_env_step_promoted(self._handle_v, actions.data_ptr(), int(act_f64), *base[2:], *outs,
                                                 self._flag if notify else None, seq if notify else 0, self._stream())
         elif descriptors_out is None and actions_out is None:
             if notify:
-                rc = self._lib.fe_env_step_notify(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
-                                                  dones.data_ptr(), self._flag, seq, self._stream())
+                rc = self._lib.fe_env_step_notify(*base, self._flag, seq, self._stream())
             else:
-                rc = self._step_fn(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr(),
-                                   self._stream())
+                rc = self._step_fn(*base, self._stream())
+        elif notify:
+            rc = self._lib.fe_env_step_traj_notify(*base, *outs, self._flag, seq, self._stream())
         else:
-            src = pos = None
-            if descriptors_out is not None:
-                src, pos = descriptors_out
-                for t, count, dt in ((src, N, torch.int64), (pos, N * A, torch.float64)):
-                    if t.dtype is not dt or t.numel() != count or not t.is_contiguous() or t.device != self._dev:
-                        raise ValueError("descriptors_out must be contiguous (int64 (N,), float64 (N, A)) tensors on the env's device")
-            if actions_out is not None and (actions_out.dtype is not torch.float32 or actions_out.numel() != N * A
-                                            or not actions_out.is_contiguous() or actions_out.device != self._dev):
-                raise ValueError("actions_out must be a contiguous float32 tensor of num_envs x num_assets elements on the env's device")
-            outs = (actions_out.data_ptr() if actions_out is not None else None, src.data_ptr() if src is not None else None,
-                    pos.data_ptr() if pos is not None else None)
-            if notify:
-                rc = self._lib.fe_env_step_traj_notify(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
-                                                       dones.data_ptr(), *outs, self._flag, seq, self._stream())
-            else:
-                rc = self._lib.fe_env_step_traj(self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(),
-                                                dones.data_ptr(), *outs, self._stream())
+            rc = self._lib.fe_env_step_traj(*base, *outs, self._stream())
         self._last_descriptors = descriptors_out  # None: the observation just returned was not recorded
         self._stepped = True
         self._generation += 1
