@@ -218,8 +218,7 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     if (!RESET_ONLY && promoted >= 0) {
         // the multi-asset tile loop for any A: its per-sleeve LDS arrays exist for A = 1 too (lds_bytes leaves them out there)
         kern = host_flag ? promoted_kernel_for<kFullNotify>(f32, env->vec) : promoted_kernel_for<kFull>(f32, env->vec);
-        const size_t S = (size_t)p.EB * p.A;
-        lds = (4 * (size_t)kStageBytes + (size_t)p.EB * 8 + S * 8 + S * 8 + S * 4 + S * 4 + (size_t)p.EB * 4 + 15) & ~(size_t)15;
+        lds = lds_bytes(p.EB, p.A, /*per_sleeve_arrays=*/true);
     }
     hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");

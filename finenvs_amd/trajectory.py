@@ -72,6 +72,7 @@ class TrajectoryBuffer:
                              if self.has_states else None)
         self._begun = False            # states=True: row 0 of the first chunk has been set (begin / a fused rollout)
         self._pending = [None, None]   # outstanding collective per chunk
+        self._deferred = None          # (chunk, group) handed over with all_gather_async(defer=True), not started yet
         self._gathered = [None, None]  # its output buffer
         self._cur = 0
         self.t = 0
@@ -320,13 +321,13 @@ class TrajectoryBuffer:
 
     def issue_deferred(self) -> None:
         """Start the collective of a chunk handed over with ``all_gather_async(defer=True)`` (no-op if there is none)."""
-        d = getattr(self, "_deferred", None)
+        d = self._deferred
         if d is not None:
             self._deferred = None
             self._issue(*d)
 
     def _wait(self, i: int) -> None:
-        d = getattr(self, "_deferred", None)
+        d = self._deferred
         if d is not None and d[0] == i:
             self.issue_deferred()
         if self._pending[i] is not None:
