@@ -36,11 +36,12 @@ def build(force: bool = False, verbose: bool = False) -> str:
     """The product library.  Takes NO tuning knobs from the environment: what is loaded by default is
     always the default build (experiments go through build_variant and an explicit path)."""
     if force or needs_build():
-        cmd = [HIPCC] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", LIB + ".tmp"]
+        tmp = f"{LIB}.{os.getpid()}.tmp"  # per process: several ranks may find the library missing at the same time
+        cmd = [HIPCC] + FLAGS + [os.path.join(HERE, s) for s in SOURCES] + ["-o", tmp]
         if verbose:
             cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         subprocess.check_call(cmd)
-        os.replace(LIB + ".tmp", LIB)  # never leave a half-written library behind
+        os.replace(tmp, LIB)  # atomic: never a half-written library, whoever finishes last wins with identical bytes
     return LIB
 
 
