@@ -14,7 +14,7 @@ Keyword-only extensions: ``num_envs`` (env n -> day n mod D), ``num_assets`` /
 ``prices`` / ``day_id`` (tensor input, multi-asset "sleeve" contract of
 DESIGN.md), ``tables`` (ready-made (D,L,4A) price/log-return tables),
 ``obs_dtype``, ``cast_actions`` (cast non-f32 actions to f32; default: float64 actions take the reference's f64
-promotion of its share tensors, other dtypes raise ValueError), ``obs_buffers`` (opt-in ring of env-owned observation buffers), ``obs_audition`` (ring mode:
+promotion of its share tensors, other dtypes raise ValueError), ``backend`` (only ``"hip"``: there is no CPU path), ``obs_buffers`` (opt-in ring of env-owned observation buffers), ``obs_audition`` (ring mode:
 extra candidate buffers to try at construction -- within a quarter of the free memory --, the fastest stay), ``redraw``, ``seed``, ``env_indices``, ``rank`` /
 ``world_size`` (contiguous env shards, one process per GPU).
 """
@@ -108,6 +108,7 @@ class TimeSeriesEnv:
         obs_audition: int = 0,
         redraw: str = "torch",
         cast_actions: bool = False,
+        backend: str = "hip",
         seed: int = 0,
         env_indices=None,
         rank: int = 0,
@@ -123,6 +124,9 @@ class TimeSeriesEnv:
         self.maintenance_margin_requirement = maintenance_margin_requirement
         self.log_return_scale_factor = 100
         self.evaluate = bool(evaluate)
+        if backend != "hip":
+            # SURVEY 8(b) names a `backend=` keyword ("hip" | a CPU restatement); this product has no CPU path on purpose
+            raise ValueError(f"backend={backend!r}: finenvs_amd runs the HIP path only (the CPU restatement is test infrastructure, oracle/)")
         if redraw not in ("torch", "device"):
             raise ValueError("redraw must be 'torch' (reference RNG stream) or 'device' (Philox, no host sync)")
         if obs_dtype not in (torch.float64, torch.float32):

@@ -100,6 +100,8 @@ def test_no_gpu_means_loud_failure_not_fallback(lib):
     assert b"no CPU path" in lib.fe_last_error()
     with pytest.raises(RuntimeError):
         finenvs_amd.TimeSeriesEnv(prices=[[1.0, 1, 1, 1]] * 50, day_id=[0] * 25 + [1] * 25, num_intervals=4)
+    with pytest.raises(ValueError, match="HIP path only"):  # SURVEY 8(b)'s backend= keyword exists; "cpu" is refused, not emulated
+        finenvs_amd.TimeSeriesEnv(prices=[[1.0, 1, 1, 1]] * 50, day_id=[0] * 25 + [1] * 25, num_intervals=4, backend="cpu")
 
 
 def test_product_never_imports_the_oracle():
