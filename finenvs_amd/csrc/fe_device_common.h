@@ -310,8 +310,8 @@ constexpr int kStageBytes = 5120;
 //   float  shr[S]  long+short after the reward step            (A > 1 only)
 //   int    flg[S]  sleeve done flag                            (A > 1 only)
 //   int    any[EB] env-level done                              (A > 1 only)
-// `per_sleeve_arrays`: the multi-asset tile loop's rew / shr / flg / any arrays (always for A > 1; the promoted kernels run
-// that loop for A = 1 as well)
+// `per_sleeve_arrays`: the multi-asset tile loop's rew / shr / flg / any arrays (always for A > 1; promoted launches with f32
+// observations run that loop for A = 1 as well)
 __host__ __device__ inline size_t lds_bytes(int EB, int A, bool per_sleeve_arrays = false) {
     size_t S = (size_t)EB * A;
     size_t b = 4 * (size_t)kStageBytes + (size_t)EB * 8 + S * 8;

@@ -180,13 +180,18 @@ static const void *kernel_for(bool f32, int vec, bool single) {
 #undef FE_PICK
 }
 
-// fe_env_step_promoted: the multi-asset tile loop (any A) with the promoted arithmetic, full forms only.
+// fe_env_step_promoted: the step kernel with the promoted arithmetic, full forms only.  `pipelined`: the single-asset
+// software pipeline (f64 observations, the reference's dtype); else the tile loop, which serves any A -- single-asset envs
+// with f32 observations take it too (the pipeline's f32 instantiation has no registers to spare for f64 actions at its 6
+// wavefronts per SIMD: it spilled).
 template <int FORM>
-static const void *promoted_kernel_for(bool f32, int vec) {
-#define FE_PICK(OT, VEC) ((const void *)fe_env_promoted_kernel<OT, VEC, FORM>)
-    if (f32) return vec == 4 ? FE_PICK(float, 4) : (vec == 2 ? FE_PICK(float, 2) : FE_PICK(float, 1));
-    return vec == 2 ? FE_PICK(double, 2) : FE_PICK(double, 1);
-#undef FE_PICK
+static const void *promoted_kernel_for(bool f32, int vec, bool pipelined) {
+#define FE_LOOP(OT, VEC) ((const void *)fe_env_promoted_kernel<OT, VEC, false, FORM>)
+    if (f32) return vec == 4 ? FE_LOOP(float, 4) : (vec == 2 ? FE_LOOP(float, 2) : FE_LOOP(float, 1));
+    if (pipelined)
+        return vec == 2 ? (const void *)fe_env_promoted_kernel<double, 2, true, FORM> : (const void *)fe_env_promoted_kernel<double, 1, true, FORM>;
+    return vec == 2 ? FE_LOOP(double, 2) : FE_LOOP(double, 1);
+#undef FE_LOOP
 }
 
 // Per-call pointers go into a local copy of the parameter block: the env object itself is not
@@ -216,9 +221,9 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
                                     : (full ? kernel_for<false, kFull>(f32, env->vec, single) : kernel_for<false, kLean>(f32, env->vec, single)));
     size_t lds = env->lds;
     if (!RESET_ONLY && promoted >= 0) {
-        // the multi-asset tile loop for any A: its per-sleeve LDS arrays exist for A = 1 too (lds_bytes leaves them out there)
-        kern = host_flag ? promoted_kernel_for<kFullNotify>(f32, env->vec) : promoted_kernel_for<kFull>(f32, env->vec);
-        lds = lds_bytes(p.EB, p.A, /*per_sleeve_arrays=*/true);
+        const bool pipelined = single && !f32;
+        kern = host_flag ? promoted_kernel_for<kFullNotify>(f32, env->vec, pipelined) : promoted_kernel_for<kFull>(f32, env->vec, pipelined);
+        if (!pipelined) lds = lds_bytes(p.EB, p.A, /*per_sleeve_arrays=*/true);
     }
     hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");

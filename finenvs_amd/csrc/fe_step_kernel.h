@@ -62,7 +62,9 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
     if constexpr (!SINGLE) lds_barrier();
     if (active && a == 0) {
         double rew;
-        if constexpr (SINGLE) {
+        if constexpr (SINGLE && PROMO) {  // num_shares is an f64 tensor: the fee is an f64 product, TSE:288-289
+            rew = s.rew - ((any ? 1.0 : 0.0) * (double)(s.sht + s.lng)) * p.comm;
+        } else if constexpr (SINGLE) {
             float fee = ((any ? 1.0f : 0.0f) * (s.sht + s.lng)) * p.c32;  // TSE:288-289
             rew = s.rew - (double)fee;
         } else {
@@ -336,12 +338,24 @@ __device__ __forceinline__ int64_t tile_at(const Params &p, int64_t k, bool last
 // Software pipeline state of the single-asset step kernel: inputs of the current tile, prefetched inputs of the
 // next one, indices of the one after.  Env numbers are recomputed from the (uniform) tile number where they are
 // needed instead of being carried through phase 2.
-struct PipeState {
+template <bool PROMO>
+struct PipeStateT {
     SleeveIn in_cur, in_nxt;
-    float action_cur, action_nxt, action_nn;  // actions run TWO tiles ahead: a caller's action buffer may be cold (a new
-                                              // trajectory slot every step costs a TLB walk + an HBM round trip, ~5 us)
+    ActionT<PROMO> action_cur, action_nxt, action_nn;  // actions run TWO tiles ahead: a caller's action buffer may be cold (a
+                                                       // new trajectory slot every step costs a TLB walk + an HBM round trip, ~5 us)
     int64_t idx1, spot1, idx2, spot2;
 };
+
+// the action of sleeve sl: f32, or -- promoted launches -- a double that is either the caller's f64 action or its f32 action
+// carried exactly (sleeve_step tells them apart by p.act_f64)
+template <bool PROMO>
+__device__ __forceinline__ ActionT<PROMO> load_action(const Params &p, int64_t sl) {
+    if constexpr (PROMO) {
+        return p.act_f64 ? reinterpret_cast<const double *>(p.actions)[sl] : (double)p.actions[sl];
+    } else {
+        return p.actions[sl];
+    }
+}
 
 // env number of lane e in tile t, and whether that lane has an env there
 __device__ __forceinline__ int64_t pipe_env_of(const Params &p, int EB, int e, int64_t t, bool &act) {
@@ -360,15 +374,15 @@ constexpr bool kActionsTwoAhead = sizeof(OT) == 8;
 // One tile of the single-asset pipeline: account it (inputs already in registers), prefetch the next tile's body and
 // the head of the one after, stream its observation.  FIRST: the workgroup's first tile, whose first phase-2
 // iteration may use table tuples loaded before the accounting (`pre`).
-template <typename OT, int VEC, bool FIRST, int FORM>
-__device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, OT *stage, PipeState &ps, int64_t tile,
+template <typename OT, int VEC, bool FIRST, int FORM, bool PROMO>
+__device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, OT *stage, PipeStateT<PROMO> &ps, int64_t tile,
                                             int64_t k, int EB, int e, int lane, int wave, PreTuples<OT> pre) {
     const int64_t n0 = tile * EB;
     const int ebt = (p.N - n0) < (int64_t)EB ? (int)(p.N - n0) : EB;
     {
         bool act0;
         const int64_t n_cur = pipe_env_of(p, EB, e, tile, act0);
-        account_core<true, FORM>(p, l, 1, e, 0, act0, n_cur, n_cur, ps.in_cur, ps.action_cur, p.rew, p.done);
+        account_core<true, FORM, PROMO>(p, l, 1, e, 0, act0, n_cur, n_cur, ps.in_cur, ps.action_cur, p.rew, p.done);
     }
     lds_barrier();
     // prefetch: body of the next tile (its head arrived during the previous phase 2), head of the one after
@@ -378,10 +392,10 @@ __device__ __forceinline__ void single_tile(const Params &p, const TileLds &l, O
     const int64_t n_nn = pipe_env_of(p, EB, e, tile_at(p, k + 2, rev), act2);
     load_body(p, 1, 0, act1, n_nxt, ps.idx1, ps.spot1, ps.in_nxt);
     if constexpr (!kActionsTwoAhead<OT>)
-        if (act1) ps.action_nxt = p.actions[n_nxt];
+        if (act1) ps.action_nxt = load_action<PROMO>(p, n_nxt);
     load_head(p, act2, n_nn, ps.idx2, ps.spot2);
     if constexpr (kActionsTwoAhead<OT>)
-        if (act2) ps.action_nn = p.actions[n_nn];
+        if (act2) ps.action_nn = load_action<PROMO>(p, n_nn);
     stream_tile<OT, VEC, true>(p, l, stage, 1, ebt, reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave,
                                FIRST && kHoistFirst<OT>, pre);
     lds_barrier();  // LDS is reused by the next tile
@@ -402,11 +416,11 @@ template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY>
 constexpr int kEnvKernelWaves = !SINGLE ? kMultiAssetWaves
                                 : (RESET_ONLY ? kRenderWaves
                                               : (sizeof(OT) == 8 ? (kHoistFirst<OT> ? 4 : kRenderWaves) : kF32StepWaves<OT, VEC>));
-// The body of fe_env_kernel (and of fe_env_promoted_kernel: PROMO, always with SINGLE = false -- the unpipelined tile loop
-// serves A = 1 as well; the promoted arithmetic is a compatibility path, not the headline: see sleeve_step).
+// The body of fe_env_kernel and of fe_env_promoted_kernel (PROMO: the arithmetic of an env whose share tensors the reference
+// has promoted to f64, see sleeve_step; full forms only).
 template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY, int FORM, bool PROMO>
 __device__ __forceinline__ void env_kernel_body(const Params &p) {
-    static_assert(!PROMO || (!SINGLE && !RESET_ONLY && form_is_full(FORM)), "promoted arithmetic: multi-asset tile loop, full forms");
+    static_assert(!PROMO || (!RESET_ONLY && form_is_full(FORM)), "promoted arithmetic: full forms of the step");
     extern __shared__ __align__(16) unsigned char smem[];
     const int A = SINGLE ? 1 : p.A;
     const int EB = p.EB;
@@ -437,13 +451,9 @@ __device__ __forceinline__ void env_kernel_body(const Params &p) {
             const bool active = e < ebt;
             const int64_t n = n0 + e;
             const int64_t sl = n * A + a;
-            if constexpr (PROMO) {
-                double act = 0.0;
-                if (active) act = p.act_f64 ? reinterpret_cast<const double *>(p.actions)[sl] : (double)p.actions[sl];
-                account_tile<SINGLE, FORM, true>(p, l, A, e, a, active, n, sl, act, p.rew, p.done);
-            } else {
-                account_tile<SINGLE, FORM>(p, l, A, e, a, active, n, sl, active ? p.actions[sl] : 0.0f, p.rew, p.done);
-            }
+            ActionT<PROMO> act = 0;
+            if (active) act = load_action<PROMO>(p, sl);
+            account_tile<SINGLE, FORM, PROMO>(p, l, A, e, a, active, n, sl, act, p.rew, p.done);
             stream_tile<OT, VEC, SINGLE>(p, l, stage, A, ebt,
                                          reinterpret_cast<OT *>(p.obs) + n0 * (int64_t)p.env_elems, lane, wave);
             lds_barrier();  // LDS is reused by the next tile
@@ -455,8 +465,8 @@ __device__ __forceinline__ void env_kernel_body(const Params &p) {
         // memory round trips.
         constexpr bool rev = form_notifies(FORM);
         int64_t tile = tile_at(p, 0, rev);
-        PipeState ps;
-        ps.action_cur = 0.0f; ps.action_nxt = 0.0f; ps.action_nn = 0.0f;
+        PipeStateT<PROMO> ps;
+        ps.action_cur = 0; ps.action_nxt = 0; ps.action_nn = 0;
         bool act0, act1;
         const int64_t n_cur = pipe_env_of(p, EB, e, tile, act0);
         const int64_t n_nxt = pipe_env_of(p, EB, e, tile_at(p, 1, rev), act1);
@@ -464,9 +474,9 @@ __device__ __forceinline__ void env_kernel_body(const Params &p) {
         // bar gather (an L2 hit) waits for them
         load_head(p, act0, n_cur, ps.idx1, ps.spot1);
         load_state(p, act0, n_cur, ps.in_cur);
-        if (act0) ps.action_cur = p.actions[n_cur];
+        if (act0) ps.action_cur = load_action<PROMO>(p, n_cur);
         if constexpr (kActionsTwoAhead<OT>)
-            if (act1) ps.action_nxt = p.actions[n_nxt];  // the second tile's action leaves with the first one's
+            if (act1) ps.action_nxt = load_action<PROMO>(p, n_nxt);  // the second tile's action leaves with the first one's
         load_bar(p, 1, 0, act0, ps.idx1, ps.spot1, ps.in_cur);
         PreTuples<OT> pre{};  // table tuples of this wavefront's first phase-2 iteration (FE_HOIST_FIRST)
         // Start-up chain of the first tile: the window descriptors need the index loads only, so they are published
@@ -495,9 +505,9 @@ __device__ __forceinline__ void env_kernel_body(const Params &p) {
         load_head(p, act1, n_nxt, ps.idx1, ps.spot1);
         // one tile per call; the workgroup's first tile is peeled (FIRST) so that `pre` dies before the loop
         if (tile < p.num_tiles) {
-            single_tile<OT, VEC, true, FORM>(p, l, stage, ps, tile, 0, EB, e, lane, wave, pre);
+            single_tile<OT, VEC, true, FORM, PROMO>(p, l, stage, ps, tile, 0, EB, e, lane, wave, pre);
             for (int64_t k = 1; (tile = tile_at(p, k, rev)) < p.num_tiles; ++k)
-                single_tile<OT, VEC, false, FORM>(p, l, stage, ps, tile, k, EB, e, lane, wave, PreTuples<OT>{});
+                single_tile<OT, VEC, false, FORM, PROMO>(p, l, stage, ps, tile, k, EB, e, lane, wave, PreTuples<OT>{});
         }
     }
     // Evaluate mode has no evaluation env; what its host reads every step is "have ALL envs terminated?" (TSE:531), a
@@ -525,10 +535,11 @@ __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONL
     env_kernel_body<OT, VEC, SINGLE, RESET_ONLY, FORM, false>(p);
 }
 
-// fe_env_step_promoted: the multi-asset tile loop (any A) with the promoted arithmetic; FORM kFull or kFullNotify
-template <typename OT, int VEC, int FORM>
-__global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, false, false>)) void fe_env_promoted_kernel(const Params p) {
-    env_kernel_body<OT, VEC, false, false, FORM, true>(p);
+// fe_env_step_promoted: the same kernel structure (single-asset pipeline / multi-asset tile loop) with the promoted
+// arithmetic; FORM kFull or kFullNotify
+template <typename OT, int VEC, bool SINGLE, int FORM>
+__global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, false>)) void fe_env_promoted_kernel(const Params p) {
+    env_kernel_body<OT, VEC, SINGLE, false, FORM, true>(p);
 }
 
 }  // namespace

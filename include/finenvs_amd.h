@@ -156,7 +156,7 @@ int fe_env_step_traj_notify(fe_env *env, const float *actions, void *obs, double
  * The caller owns the "has been promoted" bit (the Python class sets it at the first f64 step and routes every later step
  * here); the state arrays stay f32 / f64 as bound (same values).  actions: (N*A) f64 if actions_are_f64 else f32.
  * Optional outputs as fe_env_step_traj (actions_store_out only with f32 actions); host_flag / seq as fe_env_step_notify
- * (NULL: no flag).  Runs the unpipelined tile loop for every A: a compatibility path, not the fast one.
+ * (NULL: no flag).  Same kernel structure as fe_env_step (single-asset envs with f32 observations take the tile loop).
  */
 int fe_env_step_promoted(fe_env *env, const void *actions, int32_t actions_are_f64, void *obs, double *rewards,
                          int32_t *dones, float *actions_store_out, int64_t *obs_src_out, double *obs_pos_out,

@@ -294,20 +294,26 @@ def test_action_dtypes_cast_promote_or_refuse(fe, fo):
     assert_bits(t2n(o), t2n(o32), "obs")
     assert_bits(t2n(r), t2n(r32), "rewards")
     assert_bits(t2n(d), t2n(d32), "dones")
-    # promoted arithmetic vs the oracle: 3 assets (sleeve sum, shared done), small balance, f64 / f32 steps mixed
+    # promoted arithmetic vs the oracle, f64 / f32 steps mixed, small balance: 3 assets (tile loop: sleeve sum, shared done);
+    # one asset with f64 observations (the software pipeline), with f32 observations (the tile loop at A = 1) and with an odd
+    # observation size (8-byte stores)
+    for A, N, W, f32 in ((3, 257, 8, False), (1, 3000, 8, False), (1, 3000, 8, True), (1, 700, 7, False)):
+        P, LR = _tables(fo, 6, A, 40, W)
+        env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, starting_balance=900,
+                               obs_dtype=torch.float32 if f32 else torch.float64)
+        ref = fo.OracleEnv(P, LR, W, num_envs=N, evaluate=True, starting_balance=900, obs_f32=f32)
+        g = torch.Generator().manual_seed(5 + A)
+        for t in range(90):
+            a = torch.rand((N, A), generator=g, dtype=torch.float64) * 2 - 1
+            a = a if (t < 30 or t >= 60) else a.float()
+            o, r, d, _ = env.step(a.cuda())
+            o2, r2, d2, _ = ref.step(a.numpy())
+            what = f"A={A} W={W} f32={f32} step {t}"
+            assert_bits(t2n(o), o2, what + " obs"); assert_bits(t2n(r), r2, what + " rewards"); assert_bits(t2n(d), d2, what + " dones")
+            assert_bits(t2n(env.cash), ref.cash, what + " cash")
+        assert env.shares_promoted and ref.shares_f64
     P, LR = _tables(fo, 6, 3, 40, 8)
     N, A = 257, 3
-    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=8, num_envs=N, evaluate=True, starting_balance=900)
-    ref = fo.OracleEnv(P, LR, 8, num_envs=N, evaluate=True, starting_balance=900)
-    g = torch.Generator().manual_seed(5)
-    for t in range(90):
-        a = torch.rand((N, A), generator=g, dtype=torch.float64) * 2 - 1
-        a = a if (t < 30 or t >= 60) else a.float()
-        o, r, d, _ = env.step(a.cuda())
-        o2, r2, d2, _ = ref.step(a.numpy())
-        assert_bits(t2n(o), o2, f"step {t} obs"); assert_bits(t2n(r), r2, f"step {t} rewards"); assert_bits(t2n(d), d2, f"step {t} dones")
-        assert_bits(t2n(env.cash), ref.cash, f"step {t} cash")
-    assert env.shares_promoted and ref.shares_f64
     # the fused rollouts run the f32 arithmetic only: they refuse a promoted env
     from finenvs_amd.rollout import FusedLinearRollout
 

@@ -27,9 +27,11 @@ def table():
 
 
 def test_streaming_kernels_use_no_scratch(table):
-    streaming = [r for r in table if re.match(r"fe_(env|render|describe)_kernel", r["name"])]
+    streaming = [r for r in table if re.match(r"fe_(env|env_promoted|render|describe)_kernel", r["name"])]
     # 5 (dtype x pack width) x 2 (single / multi asset) x (reset + four forms of the step), + render and describe
     assert len([r for r in streaming if r["name"].startswith("fe_env_kernel")]) == 50
+    # promoted (f64-action) arithmetic: the tile loop for every (dtype, pack width), the pipeline for f64 observations; full forms
+    assert len([r for r in streaming if r["name"].startswith("fe_env_promoted_kernel")]) == (5 + 2) * 2
     assert len([r for r in streaming if r["name"].startswith("fe_render_kernel")]) == 10
     bad = [(r["name"], r["scratch"], r["vgpr_spill"]) for r in streaming if r["scratch"] != 0 or r["vgpr_spill"] != 0]
     assert not bad, f"scratch / VGPR spills in streaming kernels: {bad}"
