@@ -476,7 +476,7 @@ def lstm_actor_case():
     save_npz(os.path.join(GOLD, "lstm_actor.npz"), **out)
 
 
-def sleeves_case(fname, name, A, N, W, T, days, bars, csv_seed, action_seed, full_obs):
+def sleeves_case(fname, name, A, N, W, T, days, bars, csv_seed, action_seed, full_obs, f64_from=None, starting_balance=10000):
     """The multi-asset "sleeve" contract pinned to the reference: A reference
     envs (one per asset, same calendar) stepped side by side on column a of one (N, A) action tensor.  Observation =
     their observations concatenated along the feature axis (asset a in columns 5a..5a+4, TSE:423-445), reward = their
@@ -487,15 +487,21 @@ def sleeves_case(fname, name, A, N, W, T, days, bars, csv_seed, action_seed, ful
     write_case_csv(name, days, bars, seed=csv_seed, num_assets=A)
     envs = []
     for a in range(A):
-        e, _ = make_env(f"{name}_a{a}", W, evaluate=True)
+        e, _ = make_env(f"{name}_a{a}", W, evaluate=True, starting_balance=starting_balance)
         scale_env(e, N)
         envs.append(e)
     g = torch.Generator().manual_seed(action_seed)
+    act_f64 = []
     acts, rews, dones, obss, last_rows, full_steps = [], [], [], [], [], []
     st = {k: [] for k in ("cash", "margin", "long", "short", "spot0")}
     obs0 = torch.cat([e.reset() for e in envs], dim=2)
     for t in range(T):
-        a = (torch.rand((N, A), generator=g) * 2 - 1).float()
+        if f64_from is not None and t >= f64_from and (t - f64_from) % 9 < 5:
+            # float64 actions: every side-by-side reference promotes its share tensors (TSE:353-374); f32 steps in between
+            a = torch.rand((N, A), generator=g, dtype=torch.float64) * 2 - 1
+        else:
+            a = (torch.rand((N, A), generator=g) * 2 - 1).float()
+        act_f64.append(np.int64(a.dtype == torch.float64))
         o_l, r_l, d_l = [], [], []
         for k, e in enumerate(envs):
             # evaluate mode keeps the RNG redraw out of it; clearing the metrics before each
@@ -507,19 +513,23 @@ def sleeves_case(fname, name, A, N, W, T, days, bars, csv_seed, action_seed, ful
         r = r_l[0]
         for x in r_l[1:]:
             r = r + x  # sequential sum in asset order, f64
-        acts.append(a.numpy().copy()); rews.append(r.numpy().copy()); dones.append(d_l[0].numpy().copy())
+        acts.append(a.double().numpy().copy() if f64_from is not None else a.numpy().copy())
+        rews.append(r.numpy().copy()); dones.append(d_l[0].numpy().copy())
         obs = torch.cat(o_l, dim=2).numpy().copy()
         if full_obs or t < 3 or bool(d_l[0].any()) or t == T - 1:
             full_steps.append(t)
             obss.append(obs)
         last_rows.append(obs[:, -1, :].copy())
         for k2 in st:
-            st[k2].append(np.stack([state_of(e)[k2] for e in envs], axis=1))
+            col = np.stack([state_of(e)[k2] for e in envs], axis=1)
+            st[k2].append(col.astype(np.float64) if (f64_from is not None and k2 in ("long", "short")) else col)
     extra = {} if full_obs else {"obs_steps": np.asarray(full_steps, dtype=np.int64), "obs_last_row": np.stack(last_rows)}
+    if f64_from is not None:
+        extra["act_f64"] = np.asarray(act_f64)
     save_npz(
         os.path.join(GOLD, fname),
         W=np.int64(W), N=np.int64(N), A=np.int64(A), evaluate=np.int64(1),
-        max_shares=np.int64(5), starting_balance=np.float64(10000), commission=np.float64(0.01),
+        max_shares=np.int64(5), starting_balance=np.float64(starting_balance), commission=np.float64(0.01),
         imr=np.float64(1.5), mmr=np.float64(0.25),
         prices=np.concatenate([e.price_environments.numpy() for e in envs], axis=2),
         logret=np.concatenate([e.log_return_environments.numpy() for e in envs], axis=2),
@@ -626,6 +636,10 @@ def main():
     # shared done flag of that shape against 30 reference envs on one calendar (crosses a day end; no bankruptcies, so the
     # side-by-side references stay in step).  Full observations at a few steps, the newest window row at every step.
     sleeves_case("rollout_sleeves30.npz", "SYN_multi30", A=30, N=9, W=8, T=64, days=5, bars=40, csv_seed=47, action_seed=29, full_obs=False)
+    # the sleeve contract under the reference's f64 promotion: three reference envs side by side, float64 actions from step 3 on
+    # in runs of five with float32 steps between them (actions stored as f64 + the per-step dtype flag)
+    sleeves_case("rollout_sleeves3_f64.npz", "SYN_multi", A=3, N=20, W=8, T=70, days=6, bars=40, csv_seed=31, action_seed=12, full_obs=False,
+                 f64_from=3, starting_balance=3000)
 
     # ---------------- rounding probes (a3) ----------------
     env, _ = make_env("SYN_roll", 8, evaluate=True)

@@ -132,7 +132,7 @@ def test_real_data_ibm_spy_rollouts(name):
     _replay(g, name, host_redraw=True, check_obs_full=False)
 
 
-@pytest.mark.parametrize("name", ["rollout_sleeves3.npz", "rollout_sleeves30.npz"])
+@pytest.mark.parametrize("name", ["rollout_sleeves3.npz", "rollout_sleeves30.npz", "rollout_sleeves3_f64.npz"])
 def test_multi_asset_sleeves_equal_side_by_side_references(name):
     """The oracle's sleeve loop against A reference envs stepped side by side; rollout_sleeves30.npz = the 30-asset
     shape of BASELINE configs 3-5 (full observations at `obs_steps`, the newest window row at every step)."""
@@ -142,8 +142,10 @@ def test_multi_asset_sleeves_equal_side_by_side_references(name):
     assert env.A == A
     assert_bits(env.reset(), g["obs_reset"], "reset obs")
     full_at = {int(t): i for i, t in enumerate(g["obs_steps"])} if "obs_steps" in g else None
+    f64_steps = g.get("act_f64")  # rollout_sleeves3_f64.npz: float64 actions at these steps (the references promote, TSE:353-374)
     for t in range(g["actions"].shape[0]):
-        obs, rew, done, _ = env.step(g["actions"][t])
+        a = g["actions"][t] if (f64_steps is None or f64_steps[t]) else g["actions"][t].astype(np.float32)
+        obs, rew, done, _ = env.step(a)
         env.terminated[:] = 0  # the fixture cleared the metrics each step
         env.n_terminated[0] = 0
         what = f"sleeves step {t}"
@@ -157,9 +159,10 @@ def test_multi_asset_sleeves_equal_side_by_side_references(name):
         assert_bits(done, g["dones"][t], what + " dones")
         assert_bits(env.cash, g["cash"][t], what + " cash")
         assert_bits(env.margin, g["margin"][t], what + " margin")
-        assert_bits(env.long, g["long"][t], what + " long")
-        assert_bits(env.short, g["short"][t], what + " short")
+        assert_bits(env.long.astype(g["long"].dtype), g["long"][t], what + " long")
+        assert_bits(env.short.astype(g["short"].dtype), g["short"][t], what + " short")
     assert g["dones"].sum() > 0
+    assert (f64_steps is None) or (env.shares_f64 and 0 < int(f64_steps.sum()) < len(f64_steps))
 
 
 def test_share_change_rounding_probes():
