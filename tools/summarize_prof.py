@@ -179,8 +179,8 @@ def main():
                     f"{dev:+.1f} % (the interval includes the ~1.5 us launch boundary; the kernel's own duration does not)\n")
         f.write(f"* bench.py under the profiler: {bench['value']:.4g} env-steps/s, {bench['ms_per_step']*1e3:.2f} us/step wall (median of "
                 f"{bench['repeats'][next(iter(bench['repeats']))]['blocks']} blocks; the wall step is the LOOP launches + the fences around each block)\n")
-        f.write(f"* other instantiations in this run: " + "; ".join(
-            f"`{n}` {len(v)} calls, avg {sum(x[0] for x in v) / len(v) / 1e3:.2f} us" for n, v in sorted(by_form.items()) if n != headline_kernel) + "\n")
+        others = [f"`{n}` {len(v)} calls, avg {sum(x[0] for x in v) / len(v) / 1e3:.2f} us" for n, v in sorted(by_form.items()) if n != headline_kernel]
+        f.write("* other step-kernel instantiations in this run: " + ("; ".join(others) if others else "none") + "\n")
         f.write(f"* HBM bytes that must move per launch (observation write + state + outputs): {Bh} B x {N} envs = {Bh*N/1e6:.1f} MB "
                 f"(this is what `roofline.achieved` / `frac` divide by the launch duration)\n")
         avg = tight["avg_ns"] if tight else float(step_row["AverageNs"])
