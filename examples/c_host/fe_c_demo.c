@@ -30,6 +30,7 @@ int main(int argc, char **argv) {
     const int32_t W = argc > 2 ? atoi(argv[2]) : 16;
     const int steps = argc > 3 ? atoi(argv[3]) : 200;
     const int notify = argc > 4 && argv[4][0] == 'n';
+    const int promoted = argc > 4 && argv[4][0] == 'p'; /* float64 actions: the reference's f64 promotion, fe_env_step_promoted */
     const int32_t A = 1;
     const int64_t days = 6, bars = 50, T = days * bars;
     if (fe_device_count() < 1) { fprintf(stderr, "no HIP device\n"); return 1; }
@@ -104,6 +105,20 @@ int main(int argc, char **argv) {
     FECK(fe_env_bind_state(env, d_idx, d_spot, d_cash, d_long, d_short, d_margin, NULL, NULL, d_counters));
     FECK(fe_env_reset_obs(env, d_obs, NULL));
 
+    /* episode statistics fused into the step (PPO_agent.py:120-132) + their fixed-order read-out (146-163) */
+    float *d_running, *d_evalret;
+    double *d_acc, *d_sums, *d_act64;
+    HIPCK(hipMalloc((void **)&d_running, sizeof(float) * N));
+    HIPCK(hipMalloc((void **)&d_acc, sizeof(double) * 3 * N));
+    HIPCK(hipMalloc((void **)&d_evalret, sizeof(float) * 2));
+    HIPCK(hipMalloc((void **)&d_sums, sizeof(double) * 3));
+    HIPCK(hipMalloc((void **)&d_act64, sizeof(double) * N));
+    HIPCK(hipMemset(d_running, 0, sizeof(float) * N));
+    HIPCK(hipMemset(d_acc, 0, sizeof(double) * 3 * N));
+    HIPCK(hipMemset(d_evalret, 0, sizeof(float) * 2));
+    FECK(fe_env_bind_stats(env, d_running, d_acc, d_evalret));
+    double *h_act64 = (double *)malloc(sizeof(double) * N);
+
     float *h_act = (float *)malloc(sizeof(float) * N);
     double *h_rew = (double *)malloc(sizeof(double) * N);
     int32_t *h_done = (int32_t *)malloc(sizeof(int32_t) * N);
@@ -133,6 +148,15 @@ int main(int argc, char **argv) {
                 }
             }
             eval_dones_flag += (long long)(v & 1);
+        } else if (promoted) {
+            /* f64 actions on two steps of three; the f32 steps in between run on the promoted env too (sticky, as in the reference) */
+            const int f64 = s % 3 != 2;
+            if (f64) {
+                for (int64_t n = 0; n < N; ++n) h_act64[n] = sin(0.013 * (double)(n + 1) * (double)(s + 1));
+                HIPCK(hipMemcpy(d_act64, h_act64, sizeof(double) * N, hipMemcpyHostToDevice));
+            }
+            FECK(fe_env_step_promoted(env, f64 ? (const void *)d_act64 : (const void *)d_act, f64, d_obs, d_rew, d_done, NULL, NULL, NULL,
+                                      NULL, 0, NULL));
         } else {
             FECK(fe_env_step(env, d_act, d_obs, d_rew, d_done, NULL));
         }
@@ -153,7 +177,11 @@ int main(int argc, char **argv) {
     FECK(fe_env_launch_info(env, &grid, &block, &tile, &lds));
     printf("abi=%d N=%lld W=%d D=%lld L=%lld steps=%d grid=%d tile=%d\n", fe_version(), (long long)N, W, (long long)D,
            (long long)L, steps, grid, tile);
-    printf("reward_sum=%.17g dones=%lld cash_sum=%.17g last_obs_sum=%.17g eval_dones=%lld\n", rew_sum, dones, cash_sum, obs_sum, eval_dones);
+    double h_sums[3];
+    FECK(fe_env_stats_reduce(env, d_sums, NULL));
+    HIPCK(hipMemcpy(h_sums, d_sums, sizeof(h_sums), hipMemcpyDeviceToHost));
+    printf("reward_sum=%.17g dones=%lld cash_sum=%.17g last_obs_sum=%.17g eval_dones=%lld stat_episodes=%.17g stat_sum=%.17g stat_sumsq=%.17g\n",
+           rew_sum, dones, cash_sum, obs_sum, eval_dones, h_sums[0], h_sums[1], h_sums[2]);
     if (flag) FECK(fe_host_flag_destroy(flag));
     FECK(fe_env_destroy(env));
     return 0;
