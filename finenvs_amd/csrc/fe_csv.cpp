@@ -30,7 +30,7 @@
 
 #include "finenvs_amd.h"
 
-extern "C" int fe_set_error(int code, const char *fmt, ...);  // fe_env.hip
+extern "C" __attribute__((visibility("hidden"))) int fe_set_error(int code, const char *fmt, ...);  // fe_env.hip (library-internal)
 
 namespace {
 

@@ -233,7 +233,11 @@ __device__ __forceinline__ void sleeve_step(const Params &p, typename std::condi
     add_commission(bb, PROMO);
     cash = (float)((double)cash - (double)bb * (O + p.comm));
     sht = ns;
-    double nm = (double)(p.imr32 * sht) * O;
+    // new_margin = initial_margin_requirement * short_shares * open, TSE:376-379: the first product is in short_shares'
+    // dtype -- f32 (imr rounded to f32) until the promotion, f64 with the full-precision imr after it
+    double nm;
+    if constexpr (PROMO) nm = (p.imr * (double)sht) * O;
+    else nm = (double)(p.imr32 * sht) * O;
     cash = (float)((double)cash - (nm - margin));
     margin = nm;
 

@@ -45,6 +45,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
 #include <new>
 #include <type_traits>
 
@@ -74,6 +75,11 @@ struct fe_env {
     int grid;
     int vec;  // observation elements per 16-byte store (1 when the env size is odd)
     size_t lds;
+    size_t lds_promoted;  // dynamic LDS of the kernel fe_env_step_promoted dispatches to (== lds unless it takes the tile loop at A = 1)
+    bool promoted_used;   // sticky: fe_env_step_promoted has been called (fe_env_launch_info then describes that kernel)
+    // the observation buffer of the previous step launch: the store policy is decided per launch from how the buffers are
+    // actually used (launch_env).  Relaxed: a stale value costs one launch the other policy, never correctness.
+    mutable std::atomic<const void *> last_obs{nullptr};
     bool bound;
     int cus;              // compute units of that device
     int tile_override, grid_override, rollout_tile_override;  // fe_env_set_launch (tuning), 0 = automatic
@@ -223,7 +229,17 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     if (!RESET_ONLY && promoted >= 0) {
         const bool pipelined = single && !f32;
         kern = host_flag ? promoted_kernel_for<kFullNotify>(f32, env->vec, pipelined) : promoted_kernel_for<kFull>(f32, env->vec, pipelined);
-        if (!pipelined) lds = lds_bytes(p.EB, p.A, /*per_sleeve_arrays=*/true);
+        lds = env->lds_promoted;
+    }
+    if (!RESET_ONLY) {
+        // Store policy of a large single-asset observation (Params::obs_stream, fe_device_common.h): sc1 | nt keeps the
+        // stream out of the 256 MiB Infinity Cache, which pays when the caller ALTERNATES over buffers that together
+        // overflow it (a ring of two, fresh tensors per call) -- but a caller that rewrites ONE buffer of 128 - 256 MiB
+        // (obs_buffers=1, a C host with one d_obs) is absorbed by the cache and runs 3 % faster with plain sc1
+        // (profiles/r04_microbench/ring_alternation.txt: 27.5 vs 28.4 us).  So: stream unless this launch writes the very
+        // buffer the previous one wrote.
+        const void *prev = env->last_obs.exchange(obs, std::memory_order_relaxed);
+        if (p.obs_stream && prev == obs && (size_t)p.N * p.env_elems * (f32 ? 4 : 8) <= (256ull << 20)) p.obs_stream = 0;
     }
     hipError_t he = hipLaunchKernel(kern, dim3(env->grid), dim3(kBlock), args, lds, st);
     if (he != hipSuccess) return hip_fail(he, RESET_ONLY ? "fe_env_reset_obs launch" : "fe_env_step launch");
@@ -290,6 +306,8 @@ static int configure_launch(fe_env *env) {
     if (env->grid_override > 0) grid = env->grid_override;
     env->grid = (int)grid;
     env->lds = lds_bytes((int)EB, A);
+    // (fe_env_step_promoted: single-asset envs with f32 observations take the tile loop, which keeps per-sleeve arrays in LDS)
+    env->lds_promoted = (A == 1 && cfg.obs_is_f32 == 0) ? env->lds : lds_bytes((int)EB, A, /*per_sleeve_arrays=*/true);
     env->p.EB = (int)EB;
     env->p.num_tiles = num_tiles;
     return FE_OK;
@@ -297,8 +315,8 @@ static int configure_launch(fe_env *env) {
 
 extern "C" {
 
-// shared with fe_csv.cpp (not part of the public header)
-int fe_set_error(int code, const char *fmt, ...) {
+// shared with fe_csv.cpp: internal to the library (hidden visibility, not an exported symbol)
+__attribute__((visibility("hidden"))) int fe_set_error(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
@@ -525,6 +543,7 @@ int fe_env_step_promoted(fe_env *env, const void *actions, int32_t actions_are_f
     if (!env->bound) return fail(FE_ERR_STATE, "fe_env_step_promoted: state not bound");
     if (host_flag && env->p.eval_env < 0 && !env->cfg.evaluate)
         return fail(FE_ERR_ARG, "fe_env_step_promoted: this training-mode env has no evaluation env (a shard that does not own it)");
+    env->promoted_used = true;
     return launch_env<false>(env, reinterpret_cast<const float *>(actions), obs, rewards, dones, (hipStream_t)stream, obs_src_out,
                              obs_pos_out, actions_store_out, host_flag, seq, actions_are_f64);
 }
@@ -957,7 +976,8 @@ int fe_env_launch_info(const fe_env *env, int32_t *grid, int32_t *block, int32_t
     if (grid) *grid = env->grid;
     if (block) *block = kBlock;
     if (tile_envs) *tile_envs = env->p.EB;
-    if (lds) *lds = (int32_t)env->lds;
+    // the kernel the NEXT step dispatches to: once the env has been stepped through fe_env_step_promoted, that one
+    if (lds) *lds = (int32_t)(env->promoted_used ? env->lds_promoted : env->lds);
     return FE_OK;
 }
 

@@ -245,8 +245,7 @@ class TimeSeriesEnv:
     def set_environment_params(self, num_envs, env_indices, obs_buffers) -> None:
         """TSE:245-269: state tensors; plus the C-ABI env object."""
         dev = self._dev
-        D, L, _ = self.price_environments.shape
-        A, W = self.num_assets, self.num_intervals
+        D = self.price_environments.shape[0]
         training = not self.evaluate
         if env_indices is not None:
             idx = torch.as_tensor(env_indices, dtype=torch.int64).to(dev).contiguous().clone()
@@ -268,22 +267,32 @@ class TimeSeriesEnv:
                     idx[-1:] = first
             elif has_eval:
                 idx[-1] = redraw_day(self.seed, 0, D)
+        self._allocate_state(idx, total, lo, obs_buffers)
+
+    def _allocate_state(self, idx: torch.Tensor, total: int, lo: int, obs_buffers: int) -> None:
+        """The state tensors of TSE:245-269 for the day indices ``idx`` + the C-ABI env object bound to them.  The env keeps
+        PRIVATE references (``_cash`` ...) to the storage whose pointers ``fe_env`` holds: the public names are
+        properties over them, so nothing a caller assigns can free or detach the memory the kernel writes."""
+        dev = self._dev
+        D, L, _ = self.price_environments.shape
+        A, W = self.num_assets, self.num_intervals
+        training = not self.evaluate
         if idx.numel() and (int(idx.min()) < 0 or int(idx.max()) >= D):
             raise ValueError("env_indices out of range")
-        self.env_indices = idx
-        self.num_envs = int(idx.shape[0])
+        self._env_indices = idx
+        self._num_envs = int(idx.shape[0])
         self.global_num_envs = total
         self.env_offset = lo
-        N = self.num_envs
+        N = self._num_envs
         if N < 1:
             raise ValueError("this rank owns no envs")
         self._spot0 = torch.zeros((N,), dtype=torch.int64, device=dev)
-        self.cash = self.starting_balance * torch.ones((N, A), device=dev)
-        self.long_shares = torch.zeros((N, A), device=dev)
-        self.short_shares = torch.zeros((N, A), device=dev)
-        self.margin = torch.zeros((N, A), dtype=torch.float64, device=dev)
-        self.terminated_episodes = torch.zeros((N,), dtype=torch.uint8, device=dev)
-        self.episode_returns = torch.zeros((N,), device=dev)
+        self._cash = self.starting_balance * torch.ones((N, A), device=dev)
+        self._long = torch.zeros((N, A), device=dev)
+        self._short = torch.zeros((N, A), device=dev)
+        self._margin = torch.zeros((N, A), dtype=torch.float64, device=dev)
+        self._terminated = torch.zeros((N,), dtype=torch.uint8, device=dev)
+        self._returns = torch.zeros((N,), device=dev)
         # counters[0] = envs terminated so far (evaluate mode), counters[1] = redraw counter
         self._counters = torch.zeros((2,), dtype=torch.int64, device=dev)
         if training and self.redraw == "device":
@@ -299,12 +308,13 @@ class TimeSeriesEnv:
                                            self.log_return_environments.data_ptr(), C.byref(handle)))
         self._handle = handle
         _lib.check(self._lib.fe_env_bind_state(
-            handle, self.env_indices.data_ptr(), self._spot0.data_ptr(), self.cash.data_ptr(),
-            self.long_shares.data_ptr(), self.short_shares.data_ptr(), self.margin.data_ptr(),
-            self.terminated_episodes.data_ptr(), self.episode_returns.data_ptr(), self._counters.data_ptr()))
+            handle, self._env_indices.data_ptr(), self._spot0.data_ptr(), self._cash.data_ptr(),
+            self._long.data_ptr(), self._short.data_ptr(), self._margin.data_ptr(),
+            self._terminated.data_ptr(), self._returns.data_ptr(), self._counters.data_ptr()))
         if self.obs_dtype == torch.float32:
             # f32 observations stream from a pre-cast copy of the table (half the L2 reads, same values)
-            self._log_return_f32 = self.log_return_environments.float().contiguous()
+            if getattr(self, "_log_return_f32", None) is None:
+                self._log_return_f32 = self.log_return_environments.float().contiguous()
             _lib.check(self._lib.fe_env_bind_f32_table(handle, self._log_return_f32.data_ptr()))
         # observation ring: 0 = fresh tensor per call (reference semantics), k = k env-owned buffers
         self.obs_buffers = int(obs_buffers)
@@ -330,7 +340,28 @@ class TimeSeriesEnv:
             self._flag_word = C.c_uint64.from_address(flag.value)
         # bumped by everything that advances the env (step, a fused rollout's run): the fused rollout objects keep their
         # own observation descriptors and refuse to run on ones that another caller has made stale (rollout.py)
-        self._generation = 0
+        self._generation = getattr(self, "_generation", 0) + 1
+        # bumped when the bound storage itself is replaced (a resize through the env_indices setter): captured graphs and
+        # statistics objects hold the old pointers and refuse to run (rollout.GraphedRollout.run)
+        self._binding_epoch = getattr(self, "_binding_epoch", -1) + 1
+        self._last_descriptors, self._stepped = None, False
+
+    def _release_native(self) -> None:
+        """Destroy the C-ABI env object and its host flag (after the device has drained: the last launch may still be about
+        to write either)."""
+        h = getattr(self, "_handle", None)
+        if h is None or getattr(self, "_lib", None) is None:
+            return
+        try:
+            torch.cuda.synchronize(self._dev)
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+        if getattr(self, "_flag", None) is not None:
+            self._lib.fe_host_flag_destroy(self._flag)
+            self._flag = None
+        self._lib.fe_env_destroy(h)
+        self._handle = None
+        self._handle_v = None
 
     def audition_ring(self, extra: int = 2, budget_bytes: Optional[int] = None, min_gain: float = 0.03) -> None:
         """Ring mode only (also what ``obs_audition=`` runs at construction).  HBM write bandwidth on MI355X depends on where a buffer lies (the same store kernel runs
@@ -390,7 +421,9 @@ class TimeSeriesEnv:
     def print(self) -> None:
         """Attribute dump, the reference's BaseObject.print (finenvs/base_object.py:7-9); device tensors
         are summarised by shape and dtype instead of being copied to the host and printed."""
-        for key in sorted(vars(self)):
+        public = ("num_envs", "env_indices", "env_pointers", "env_spots", "cash", "long_shares", "short_shares", "margin",
+                  "terminated_episodes", "episode_returns")
+        for key in sorted([k for k in vars(self) if not k.startswith("_")] + list(public)):
             val = getattr(self, key)
             if isinstance(val, torch.Tensor):
                 val = f"Tensor{tuple(val.shape)} {str(val.dtype).replace('torch.', '')} on {val.device}"
@@ -410,17 +443,7 @@ class TimeSeriesEnv:
         return self.launch_info()
 
     def __del__(self):
-        h = getattr(self, "_handle", None)
-        if h is not None and getattr(self, "_lib", None) is not None:
-            if getattr(self, "_flag", None) is not None:
-                try:  # the last launch may still be about to write the flag
-                    torch.cuda.synchronize(self._dev)
-                except Exception:  # noqa: BLE001  (interpreter shutdown)
-                    pass
-                self._lib.fe_host_flag_destroy(self._flag)
-                self._flag = None
-            self._lib.fe_env_destroy(h)
-            self._handle = None
+        self._release_native()
 
     def _poll_flag(self, shift: int, seq: int) -> int:
         """The host flag's word once its sequence field (bits ``shift`` and up) carries ``seq``."""
@@ -437,27 +460,155 @@ class TimeSeriesEnv:
         evaluation env's done flag (TSE:510).  The kernel writes it a few microseconds after it starts."""
         return bool(self._poll_flag(1, seq) & 1)
 
-    # ------------------------------------------------------------------ reference-compatible views
+    # ------------------------------------------------------------------ public state (TSE:245-269)
+    # The reference keeps its state in plain attributes and callers REBIND them (`env.cash = S * torch.ones(N, 1)`, SURVEY
+    # Appendix B scales an env to N copies that way).  Here fe_env holds raw device pointers, so the public names are
+    # properties over env-owned storage: the getter returns the bound tensor itself (in-place edits reach the kernel), the
+    # setter COPIES the assigned values into it -- cast to the dtype the reference ends up holding (cash / shares f32,
+    # margin f64, TSE:376-383) -- and the storage can neither be freed nor detached by an assignment.  Pointers stay
+    # stable, so captured hipGraphs stay valid.  Assigning `env_indices` of another length resizes the env.
+    def _assign(self, name: str, bound: torch.Tensor, value) -> None:
+        v = torch.as_tensor(value)
+        if v.numel() != bound.numel():
+            raise ValueError(f"{name}: expected {bound.numel()} values ({tuple(bound.shape)}; the reference's shape is "
+                             f"({self._num_envs}, 1) per asset), got {tuple(v.shape)}"
+                             + ("" if name == "env_indices" else " -- assign env_indices first to resize the env"))
+        bound.copy_(v.to(device=self._dev).reshape(bound.shape))  # copy_ casts (f32 margin zeros -> f64, bool -> u8 ...)
+
+    @property
+    def num_envs(self) -> int:
+        return self._num_envs
+
+    @num_envs.setter
+    def num_envs(self, n) -> None:
+        # (the reference's recipe assigns num_envs after env_indices: nothing to do then)
+        if int(n) != self._num_envs:
+            raise ValueError(f"num_envs is {self._num_envs}: it follows env_indices -- assign env_indices ({int(n)} day "
+                             "indices) to resize the env")
+
+    @property
+    def env_indices(self) -> torch.Tensor:
+        """(N,) int64 day index of every env (TSE:246-257)."""
+        return self._env_indices
+
+    @env_indices.setter
+    def env_indices(self, value) -> None:
+        idx = torch.as_tensor(value).to(device=self._dev, dtype=torch.int64).reshape(-1).contiguous()
+        D = self.price_environments.shape[0]
+        if idx.numel() < 1 or int(idx.min()) < 0 or int(idx.max()) >= D:
+            raise ValueError(f"env_indices must be day indices in [0, {D})")
+        if idx.numel() == self._num_envs:
+            self._env_indices.copy_(idx)
+            return
+        # another length: the reference's way of scaling an env (rebinding every state tensor) -- here the env object is
+        # rebuilt for the new N with every account in its initial state (the recipe's other assignments then match)
+        if self.world_size != 1:
+            raise ValueError("resizing a sharded env (world_size > 1) is not supported: construct it with num_envs=")
+        self._release_native()
+        self._eval_env = idx.numel() - 1 if not self.evaluate else -1
+        self._allocate_state(idx.clone(), idx.numel(), 0, self.obs_buffers)
+
+    @property
+    def cash(self) -> torch.Tensor:
+        """(N, A) float32 (the reference: (N, 1))."""
+        return self._cash
+
+    @cash.setter
+    def cash(self, value) -> None:
+        self._assign("cash", self._cash, value)
+
+    @property
+    def margin(self) -> torch.Tensor:
+        """(N, A) float64: what the reference's margin is from its first step on (TSE:376-383)."""
+        return self._margin
+
+    @margin.setter
+    def margin(self, value) -> None:
+        self._assign("margin", self._margin, value)
+
+    @property
+    def long_shares(self) -> torch.Tensor:
+        """(N, A) float32 share counts; once a float64-action step has run (``shares_promoted``) a float64 COPY of them, as
+        the reference's tensor is float64 from then on (TSE:361; it rebinds the attribute every step, so no caller can rely
+        on aliasing it).  Write through assignment (``env.long_shares = t``), not into the returned copy."""
+        return self._long.double() if self.shares_promoted else self._long
+
+    @long_shares.setter
+    def long_shares(self, value) -> None:
+        self._assign("long_shares", self._long, value)
+
+    @property
+    def short_shares(self) -> torch.Tensor:
+        """See ``long_shares`` (TSE:375)."""
+        return self._short.double() if self.shares_promoted else self._short
+
+    @short_shares.setter
+    def short_shares(self, value) -> None:
+        self._assign("short_shares", self._short, value)
+
+    @property
+    def terminated_episodes(self) -> torch.Tensor:
+        """(N,) bool view of the kernel's u8 flags (TSE:272-274)."""
+        return self._terminated.view(torch.bool)
+
+    @terminated_episodes.setter
+    def terminated_episodes(self, value) -> None:
+        v = torch.as_tensor(value)
+        self._assign("terminated_episodes", self._terminated, v != 0)
+        self._counters[0] = self._terminated.sum()
+
+    @property
+    def episode_returns(self) -> torch.Tensor:
+        """(N,) float32 (TSE:275)."""
+        return self._returns
+
+    @episode_returns.setter
+    def episode_returns(self, value) -> None:
+        self._assign("episode_returns", self._returns, value)
+
     @property
     def env_spots(self) -> torch.Tensor:
-        """(N, W) window row indices; the reference stores this dense array (TSE:261-263)."""
+        """(N, W) window row indices; the reference stores this dense array (TSE:261-263).  Derived from the one int64 per
+        env the kernel keeps: never streamed."""
         return self._spot0.unsqueeze(1) + torch.arange(self.num_intervals, device=self._dev)
+
+    @env_spots.setter
+    def env_spots(self, value) -> None:
+        v = torch.as_tensor(value).to(device=self._dev, dtype=torch.int64)
+        N, W = self._num_envs, self.num_intervals
+        if tuple(v.shape) != (N, W):
+            raise ValueError(f"env_spots must be ({N}, {W}), got {tuple(v.shape)}")
+        first = v[:, 0].contiguous()
+        L = self.price_environments.shape[1]
+        if not torch.equal(v, first.unsqueeze(1) + torch.arange(W, device=self._dev)):
+            raise ValueError("env_spots rows must be consecutive (spot0 + arange(W)): the window is the only shape the "
+                             "reference's own step keeps (TSE:282, 515-521)")
+        if int(first.min()) < 0 or int(first.max()) + W >= L:
+            raise ValueError(f"env_spots out of range: every window needs one bar after it (spot0 + {W} < {L})")
+        self._spot0.copy_(first)
 
     @property
     def env_pointers(self) -> torch.Tensor:
         """Steps since the last reset; always equal to env_spots[:, 0] (TSE:281-282, 514)."""
         return self._spot0.clone()
 
+    @env_pointers.setter
+    def env_pointers(self, value) -> None:
+        # a write-only counter in the reference (TSE:258, 281, 514: never read); here it is env_spots[:, 0]
+        v = torch.as_tensor(value).to(device=self._dev, dtype=torch.int64).reshape(-1)
+        if v.numel() != self._num_envs or not torch.equal(v, self._spot0):
+            raise ValueError("env_pointers is derived (== env_spots[:, 0]): assign env_spots to move the windows")
+
     def reset_evaluation_metrics(self) -> None:
         """TSE:271-275."""
-        self.terminated_episodes.zero_()
-        self.episode_returns.zero_()
+        self._terminated.zero_()
+        self._returns.zero_()
         self._counters[0] = 0
 
     # ------------------------------------------------------------------ hot path
     def _next_obs(self) -> torch.Tensor:
         if self.obs_buffers == 0:
-            return torch.empty((self.num_envs, self.num_intervals, 5 * self.num_assets), dtype=self.obs_dtype,
+            return torch.empty((self._num_envs, self.num_intervals, 5 * self.num_assets), dtype=self.obs_dtype,
                                device=self._dev)
         buf = self._obs_ring[self._obs_next]
         self._obs_next = (self._obs_next + 1) % self.obs_buffers
@@ -547,7 +698,7 @@ class TimeSeriesEnv:
         for a trajectory that keeps states without their bytes (``TrajectoryBuffer(states=True).state_slot()``);
         ``actions_out`` (N, A) f32 receives a copy of the actions -- ``agent.store``'s action field written by the kernel
         that reads the actions anyway, so the policy's output can stay where the policy wrote it."""
-        N, A = self.num_envs, self.num_assets
+        N, A = self._num_envs, self.num_assets
         act_f64 = False
         if actions.dtype is not torch.float32:
             if self.cast_actions:
@@ -557,9 +708,9 @@ class TimeSeriesEnv:
                 # and long_shares / short_shares are REBOUND to f64 tensors -- for the life of the env, also under later
                 # f32 actions -- which makes its commission products and the liquidation fee f64 products
                 # (fe_env_step_promoted; pinned by rollout_f64_actions.npz).  This env keeps its share tensors f32 (the
-                # counts are small integers: same values) and remembers the promotion.
+                # counts are small integers: same values) and remembers the promotion -- once the step has actually been
+                # launched (a call refused by the validation below must not promote the env).
                 act_f64 = True
-                self.shares_promoted = True
             else:
                 raise ValueError(f"actions must be float32 or float64, got {actions.dtype} (the reference would compute its "
                                  "share counts in that dtype; construct the env with cast_actions=True to have them cast to float32)")
@@ -607,7 +758,7 @@ class TimeSeriesEnv:
         outs = (actions_out.data_ptr() if actions_out is not None else None, src.data_ptr() if src is not None else None,
                 pos.data_ptr() if pos is not None else None)
         base = (self._handle_v, actions.data_ptr(), obs.data_ptr(), rewards.data_ptr(), dones.data_ptr())
-        if self.shares_promoted:
+        if act_f64 or self.shares_promoted:
             rc = self._lib.fe_env_step_promoted(self._handle_v, actions.data_ptr(), int(act_f64), *base[2:], *outs,
                                                 self._flag if notify else None, seq if notify else 0, self._stream())
         elif descriptors_out is None and actions_out is None:
@@ -624,6 +775,8 @@ class TimeSeriesEnv:
         self._generation += 1
         if rc != 0:
             _lib.check(rc)
+        if act_f64:
+            self.shares_promoted = True  # (the reference has just rebound long_shares / short_shares to f64 tensors, TSE:361, 375)
         info: Dict = {}
         if self.evaluate and not getattr(self, "_defer_evaluation_check", False):
             # (GraphedRollout defers this host read to the end of a K-step replay: the per-env bookkeeping already ran in
@@ -633,7 +786,7 @@ class TimeSeriesEnv:
             # TSE:504-513: the eval env redraws a day from torch's global generator when it finishes
             if self._eval_env_done(seq) if notify else bool(dones[self._eval_env].item()):
                 D = self.price_environments.shape[0]
-                self.env_indices[self._eval_env : self._eval_env + 1] = torch.randint(0, D, (1,), device=self._dev)
+                self._env_indices[self._eval_env : self._eval_env + 1] = torch.randint(0, D, (1,), device=self._dev)
         return (obs, rewards, dones, info)
 
     def _terminated_count(self, seq: int) -> int:
@@ -646,7 +799,7 @@ class TimeSeriesEnv:
         torch.all(terminated) test and the hand-over of the returns.  ``terminated``: the count if the caller already
         has it (step() reads it from the host flag); else one device-to-host read."""
         if (int(self._counters[0].item()) if terminated is None else terminated) == self.num_envs:
-            info = {"returns": self.episode_returns.clone()}
+            info = {"returns": self._returns.clone()}
             self.reset_evaluation_metrics()
             return info
         return {}

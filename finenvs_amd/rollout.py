@@ -53,6 +53,10 @@ class GraphedRollout:
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self._iterate(record=True)
+        # what the graph froze: the kernel env.step dispatched to (f32 or promoted share arithmetic) and the pointers of the
+        # env's bound state -- run() refuses to replay once either has changed
+        self._captured_promoted = bool(env.shares_promoted)
+        self._captured_epoch = env._binding_epoch
         # self.obs now names the static buffer holding the newest observation after each replay
 
     def _iterate(self, record: bool) -> None:
@@ -89,6 +93,14 @@ class GraphedRollout:
     def run(self) -> torch.Tensor:
         """Replay the K captured steps; returns the newest observation (a static buffer).  In evaluate mode
         ``self.info`` then holds ``{"returns": ...}`` if every env has finished its episode by now (TSE:523-536), else {}."""
+        env = self.env
+        if env.shares_promoted != self._captured_promoted:
+            raise RuntimeError("the env was stepped with float64 actions after this graph was captured: the reference computes its "
+                               "commissions in f64 from then on (fe_env_step_promoted) while the captured launches run the f32 "
+                               "arithmetic -- capture a new GraphedRollout")
+        if env._binding_epoch != self._captured_epoch:
+            raise RuntimeError("the env was resized (env_indices assigned with another length) after this graph was captured: its "
+                               "launches point at the old state -- capture a new GraphedRollout")
         self.graph.replay()
         # the replay advanced the env K steps without passing through env.step(): fused rollout objects sharing this env
         # must see their observation descriptors as stale (_FusedEvaluation._begin_run).  Callers that step through
@@ -217,15 +229,26 @@ class _FusedEvaluation:
         """Point the descriptors at the observation ``env.reset()`` would render now."""
         from . import _lib
 
+        self._check_epoch()
         _lib.check(self.env._lib.fe_env_describe(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
                                                  self.env._stream()))
         self._seen_generation = self.env._generation
+
+    def _check_epoch(self) -> None:
+        """This object's descriptor arrays are sized for the env as it was when the object was made (its constructor's
+        ``sync_from_env`` records the env's binding epoch): after a resize they are the wrong length for every kernel."""
+        if getattr(self, "_epoch", None) is None:
+            self._epoch = self.env._binding_epoch
+        elif self._epoch != self.env._binding_epoch:
+            raise RuntimeError("the env was resized (env_indices assigned with another length) after this rollout object was made: "
+                               "construct a new one")
 
     def _begin_run(self) -> None:
         """A fused rollout keeps its OWN observation descriptors (what its policy sees next) but reads the account state
         from the env's shared arrays.  If anything else advanced the env since this object last looked -- ``env.step``,
         another rollout object's ``run`` -- the two no longer belong together and the policy would act on a stale
         observation while the accounting uses the current state: refuse instead of running on silently."""
+        self._check_epoch()
         if getattr(self.env, "shares_promoted", False):
             raise RuntimeError("this env was stepped with float64 actions: the reference computes its commissions in f64 from then on "
                                "(fe_env_step_promoted); the fused rollouts run the f32 arithmetic only")
@@ -242,6 +265,7 @@ class _FusedEvaluation:
         """The (N, W, 5A) observation the next policy evaluation will see."""
         from . import _lib
 
+        self._check_epoch()
         obs = self.env._next_obs()
         _lib.check(self.env._lib.fe_env_render(self.env._handle, self.obs_src.data_ptr(), self.obs_pos.data_ptr(),
                                                obs.data_ptr(), self.env._stream()))

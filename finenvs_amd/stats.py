@@ -35,12 +35,21 @@ class EpisodeStats:
         self._eval = torch.zeros((2,), dtype=torch.float32, device=dev)
         _lib.check(env._lib.fe_env_bind_stats(env._handle, self.running_returns.data_ptr(), self._acc.data_ptr(),
                                               self._eval.data_ptr()))
+        self._epoch = env._binding_epoch
+
+    def _check_bound(self) -> None:
+        if self.env._binding_epoch != self._epoch:
+            raise RuntimeError("the env was resized (env_indices assigned with another length) after this EpisodeStats was bound: "
+                               "create a new one")
 
     def close(self) -> None:
+        if self.env._binding_epoch != self._epoch:
+            return  # the env object these buffers were bound to is gone
         _lib.check(self.env._lib.fe_env_bind_stats(self.env._handle, None, None, None))
 
     def read(self, reset: bool = True) -> Dict[str, float]:
         """One D2H copy: what PPOAgent.log_progress prints (PPO_agent.py:146-163)."""
+        self._check_bound()
         _lib.check(self.env._lib.fe_env_stats_reduce(self.env._handle, self._sums.data_ptr(), self.env._stream()))
         acc = self._sums.cpu()
         ev = self._eval.cpu()

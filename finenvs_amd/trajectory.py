@@ -277,6 +277,7 @@ class TrajectoryBuffer:
         ``(actions, rewards, dones, obs_src (G, T + 1, n), obs_pos (G, T + 1, n, A), packed)``."""
         import torch.distributed as dist
 
+        self.issue_deferred()  # collectives leave in program order on every rank: a deferred chunk goes first
         G = dist.get_world_size(group)
         if out is None:
             out = torch.empty((G, self._nbytes), dtype=torch.uint8, device=self.device)
@@ -294,7 +295,7 @@ class TrajectoryBuffer:
         returns the result; a chunk is waited for automatically before it is refilled.
 
         ``defer=True`` only switches chunks now; the collective itself is started by ``issue_deferred()`` (or by the
-        next wait / drain / gather, whichever comes first).  Starting a collective costs the HOST 20 - 30 us; a loop
+        next wait / drain / gather -- the blocking ``all_gather`` included --, whichever comes first).  Starting a collective costs the HOST 20 - 30 us; a loop
         that calls it before it has queued the next steps leaves the GPU idle for that long, so a rollout loop defers it
         until a couple of steps of the new chunk are in the queue (bench.py: the world-1 RCCL path 1.99 -> 2.1 G env-steps/s
         together with the stream-ordered fence)."""

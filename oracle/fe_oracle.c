@@ -195,7 +195,9 @@ static inline void sleeve_step(const fo_config *c, float action, double action64
     FO_ADD_COMMISSION(bb, sh64);
     cash = (float)((double)cash - (double)bb * (O + comm_d));
     sht = ns;
-    double nm = (double)(imr32 * sht) * O;
+    /* new_margin = imr * short_shares * open (TSE:376-379): the first product is in short_shares' dtype -- an f32 product
+     * with the f32-rounded imr until the promotion, an f64 product with the full imr after it */
+    double nm = sh64 ? (imr * (double)sht) * O : (double)(imr32 * sht) * O;
     cash = (float)((double)cash - (nm - margin));
     margin = nm;
 

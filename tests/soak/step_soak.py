@@ -60,6 +60,9 @@ for case in range(cases):
         continue
     idx = rng.integers(0, D, N)
     kw = dict(num_intervals=W, evaluate=evaluate, starting_balance=balance)
+    if rng.integers(0, 2):  # economics that are not exact in f32 (the promoted path's f64 products differ from the f32 ones)
+        kw.update(initial_margin_requirement=float(rng.choice([1.4, 1.1, 1.7])), per_share_commission=float(rng.choice([0.035, 0.013])),
+                  maintenance_margin_requirement=float(rng.choice([0.25, 0.3])))
     ref = fo.OracleEnv(P, LR, env_indices=idx, obs_f32=f32, redraw_mode=1, seed=case, **kw)
     env = finenvs_amd.TimeSeriesEnv(tables=(P, LR), env_indices=idx, redraw="device", seed=case,
                                     obs_dtype=torch.float32 if f32 else torch.float64, **kw)

@@ -539,3 +539,22 @@ def test_env_objects_can_be_driven_from_different_host_threads(fe, fo):
     for seed in range(4):
         assert together[seed][0] == alone[seed][0], seed
         assert torch.equal(together[seed][1], alone[seed][1]), seed
+
+
+def test_store_policy_follows_how_the_buffers_are_used_not_what_is_stored(fe, fo):
+    """A single-asset observation of 128 - 256 MiB is stored sc1 | nt when the caller alternates over buffers (a ring of two
+    overflows the 256 MiB Infinity Cache) and plain sc1 when it rewrites the SAME buffer launch after launch (the cache
+    absorbs it) -- decided per launch in launch_env from the previous launch's pointer (advisor, round 4).  The policy is a
+    cache hint: an env that rewrites one buffer and an env that alternates over two produce identical bytes."""
+    P, LR = _tables(fo, 6, 1, 100, 64)
+    N, W = 65536, 64  # 168 MB per f64 observation: the size class the policy applies to
+    one = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_buffers=1)
+    two = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_buffers=2)
+    g = torch.Generator(device="cuda:0").manual_seed(5)
+    assert torch.equal(one.reset(), two.reset())
+    for t in range(5):
+        a = (torch.rand((N, 1), generator=g, device="cuda:0") * 2 - 1).float()
+        o1, r1, d1, _ = one.step(a)
+        o2, r2, d2, _ = two.step(a)
+        assert o1.data_ptr() == one._obs_ring[0].data_ptr()
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), f"step {t}"

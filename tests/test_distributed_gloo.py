@@ -95,6 +95,17 @@ def _worker(rank, world, port, q, N_TOTAL):
         buf.all_gather_async(defer=True)  # ... and so does drain()
         buf.drain()
         ok &= buf._deferred is None and buf._pending == [None, None]
+        # ... and the BLOCKING gather: a chunk still deferred leaves before it (program order of collectives on every rank)
+        buf.clear()
+        _fill(buf, lo + 5000, n)
+        buf.all_gather_async(defer=True)
+        _fill(buf, lo + 6000, n)
+        a6, r6, d6, _ = buf.all_gather()      # the chunk being filled now
+        ok &= buf._deferred is None and buf._pending[1 - buf._cur] is not None
+        ok &= all(float(r6[rr][0, 0]) == (shard_range(N_TOTAL, rr, world)[0] + 6000) * 0.5 for rr in range(world))
+        a7, r7, d7 = buf.wait_gathered()      # ... and the deferred one arrived too
+        ok &= all(float(r7[rr][0, 0]) == (shard_range(N_TOTAL, rr, world)[0] + 5000) * 0.5 for rr in range(world))
+        buf.drain()
         # the eval env (last global env) is owned by the last rank only
         owns_eval = hi == N_TOTAL
         ok &= owns_eval == (rank == world - 1)

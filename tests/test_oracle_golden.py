@@ -322,14 +322,32 @@ def _replay_f64_actions(g, promoted: bool):
     return None
 
 
-def test_float64_actions_follow_the_references_dtype_promotion():
-    """rollout_f64_actions.npz: the reference stepped with float64 actions (steps 0-59), then float32 actions on the env
+@pytest.mark.parametrize("fname", ["rollout_f64_actions.npz", "rollout_f64_actions_econ.npz"])
+def test_float64_actions_follow_the_references_dtype_promotion(fname):
+    """rollout_f64_actions.npz (default economics) / rollout_f64_actions_econ.npz (imr 1.4, commission 0.035: neither exact in
+    f32, so `imr * short_shares` -- an f64 product once short_shares is f64, TSE:376-379 -- differs from the f32 product): the reference stepped with float64 actions (steps 0-59), then float32 actions on the env
     whose share tensors that promoted to f64 (60-99), then float64 again.  The oracle's promoted arithmetic
     (fo_step_ex: commission products, short-entry commission and liquidation fee in f64; share change in the actions'
     dtype) reproduces every reward, done flag, state value and observation row bit for bit -- and the plain f32
     arithmetic does NOT (the fixture can tell the two apart), which is why the build no longer casts f64 actions."""
-    g = load_golden("rollout_f64_actions.npz")
+    g = load_golden(fname)
     assert int(g["act_f64"].sum()) == 90 and g["dones"].sum() > 100
     assert _replay_f64_actions(g, promoted=True) is None
     diff = _replay_f64_actions(g, promoted=False)
-    assert diff is not None and diff[1] in ("rewards", "cash"), diff
+    assert diff is not None and diff[1] in ("rewards", "cash", "margin"), diff
+    if fname.endswith("_econ.npz"):
+        # the fixture separates the f64 `imr * short_shares` product from the f32 one: some margin the reference holds is
+        # not what (double)((float)imr * short) * open gives for the same short count and bar
+        imr, W = float(g["imr"]), int(g["W"])
+        idx, last = g["env_idx"], g["spot0"] + W - 1
+        found = False
+        for t in range(1, 60):
+            keep = (g["dones"][t] == 0) & (g["short"][t] > 0) & (g["short"][t] == g["short"][t - 1])
+            if not keep.any():
+                continue
+            O = g["prices"][idx[t - 1][keep], last[t][keep], 0]
+            sh = g["short"][t][keep]
+            m32 = (np.float32(imr) * sh.astype(np.float32)).astype(np.float64) * O
+            m64 = (imr * sh) * O
+            found |= bool((m32 != m64).any())
+        assert found

@@ -1,0 +1,294 @@
+"""GPU tests of the PUBLIC STATE attributes (TSE:245-269; SURVEY 8(b): "state tensors ... are public attributes in the
+reference"): the reference's callers REBIND `env.cash`, `env.long_shares`, `env.env_indices` ... -- SURVEY Appendix B
+scales an env to N copies exactly that way (and oracle/make_goldens.py::scale_env did so to the reference itself to
+produce the stress fixtures).  Here fe_env holds raw device pointers, so the names are properties: assignment copies into
+env-owned storage that can be neither freed nor detached; assigning `env_indices` of another length resizes the env.
+"""
+import gc
+
+import numpy as np
+import pytest
+import torch
+
+from tests.helpers import assert_bits, econ_kwargs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def fe():
+    import finenvs_amd
+
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return finenvs_amd
+
+
+@pytest.fixture(scope="module")
+def fo():
+    from oracle import fe_oracle
+
+    fe_oracle.build()
+    return fe_oracle
+
+
+def t2n(t):
+    return t.detach().cpu().numpy()
+
+
+def appendix_b_recipe(env, N: int) -> None:
+    """SURVEY.md Appendix B ("scale to N envs (mirrors TSE:246-269)"), VERBATIM -- the statements a user of the reference
+    writes against the reference's attributes, in its order, with its (N, 1) shapes and its f32 margin zeros.  (CPU tensors,
+    as in the recipe: the reference there runs on the CPU; a drop-in has to take them.)"""
+    D = env.price_environments.shape[0]
+    W = env.num_intervals
+    S = env.starting_balance
+    env.env_indices = torch.arange(N) % D
+    env.num_envs = N
+    env.env_pointers = torch.zeros((N,), dtype=torch.int64)
+    env.env_spots = torch.arange(0, W).repeat(N, 1)
+    env.cash = S * torch.ones((N, 1))
+    env.long_shares = torch.zeros((N, 1))
+    env.short_shares = torch.zeros((N, 1))
+    env.margin = torch.zeros((N, 1))
+    if env.evaluate:
+        env.reset_evaluation_metrics()
+
+
+@pytest.mark.parametrize("prebuilt", [False, True])
+def test_appendix_b_recipe_then_the_references_own_rollout(fe, prebuilt):
+    """rollout_stress_400.npz was produced by applying this very recipe to the REFERENCE (N = 48 copies of a 7-day env) and
+    stepping it 120 times.  The same recipe applied to a constructed HIP env -- natively sized (N = D: the assignment of
+    env_indices resizes it) or already built with num_envs = 48 (the assignments copy) -- then reproduces the reference's
+    rewards, dones, state and observations bit for bit."""
+    g = load_golden("rollout_stress_400.npz")
+    W, N = int(g["W"]), int(g["N"])
+    env = fe.TimeSeriesEnv(tables=(g["prices"], g["logret"]), num_intervals=W, evaluate=True, **econ_kwargs(g),
+                           **({"num_envs": N} if prebuilt else {}))
+    D = env.price_environments.shape[0]
+    assert env.num_envs == (N if prebuilt else D)
+    ptrs = [t.data_ptr() for t in (env.cash, env.margin, env.long_shares, env.short_shares, env.env_indices)]
+    epoch = env._binding_epoch
+    appendix_b_recipe(env, N)
+    assert env.num_envs == N and env.get_env_args()["num_envs"] == N
+    if prebuilt:  # nothing was re-bound: the kernel's pointers are the ones bound at construction
+        assert [t.data_ptr() for t in (env.cash, env.margin, env.long_shares, env.short_shares, env.env_indices)] == ptrs
+        assert env._binding_epoch == epoch
+    else:
+        assert env._binding_epoch == epoch + 1
+    assert env.cash.dtype is torch.float32 and env.margin.dtype is torch.float64 and tuple(env.cash.shape) == (N, 1)
+    assert env.terminated_episodes.dtype is torch.bool and env.episode_returns.dtype is torch.float32
+    assert_bits(t2n(env.reset()), g["obs_reset"], "reset obs")
+    for t in range(g["actions"].shape[0]):
+        a = torch.from_numpy(g["actions"][t].reshape(N, 1)).to(env.device)
+        obs, rew, done, info = env.step(a)
+        what = f"recipe (prebuilt={prebuilt}) step {t}"
+        assert_bits(t2n(obs), g["obs"][t], what + " obs")
+        assert_bits(t2n(rew), g["rewards"][t], what + " rewards")
+        assert_bits(t2n(done), g["dones"][t], what + " dones")
+        assert_bits(t2n(env.cash).reshape(-1), g["cash"][t], what + " cash")
+        assert_bits(t2n(env.margin).reshape(-1), g["margin"][t], what + " margin")
+        assert_bits(t2n(env.long_shares).reshape(-1), g["long"][t], what + " long")
+        assert_bits(t2n(env.short_shares).reshape(-1), g["short"][t], what + " short")
+        assert_bits(t2n(env.env_spots[:, 0]), g["spot0"][t], what + " spot0")
+        assert_bits(t2n(env.env_indices), g["env_idx"][t], what + " env_idx")
+    assert g["dones"].sum() > 100
+
+
+@pytest.mark.parametrize("A,training", [(1, False), (1, True), (3, False)])
+def test_appendix_b_recipe_then_100_steps_against_the_oracle(fe, fo, A, training):
+    """The recipe at a size the fixtures do not hold (N = 1000 from a 5-day env; multi-asset: (N, A) state, so the recipe's
+    (N, 1) tensors only fit A = 1 and the multi-asset caller assigns (N, A)), training mode included (the evaluation env
+    is the LAST env of the resized batch, TSE:253-257, 510), against the oracle for 100 steps, bit for bit."""
+    from finenvs_amd.data import synthetic
+
+    W, N = 8, 1000
+    prices, day_id, _ = synthetic.synthetic_series(5, A, 40, 99)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    D = P.shape[0]
+    torch.manual_seed(5)
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, evaluate=not training, starting_balance=900.0, redraw="device", seed=3)
+    assert env.num_envs == D + (1 if training else 0)
+    if A == 1:
+        appendix_b_recipe(env, N)
+    else:
+        env.env_indices = torch.arange(N) % D
+        env.cash = env.starting_balance * torch.ones((N, A))
+        env.long_shares = torch.zeros((N, A))
+        env.short_shares = torch.zeros((N, A))
+        env.margin = torch.zeros((N, A))
+    assert env._eval_env == (N - 1 if training else -1)
+    ref = fo.OracleEnv(P, LR, W, env_indices=np.arange(N) % D, evaluate=not training, starting_balance=900.0, redraw_mode=1, seed=3)
+    ref.redraw_counter[0] = int(env._counters[1])  # (a resize keeps the device generator's draw 0 for the first day)
+    gen = torch.Generator().manual_seed(17)
+    assert_bits(t2n(env.reset()), ref.reset(), "reset obs")
+    dones = 0
+    for t in range(100):
+        a = (torch.rand((N, A), generator=gen) * 2 - 1).float()
+        o, r, d, i = env.step(a.to(env.device))
+        o2, r2, d2, i2 = ref.step(a.numpy())
+        what = f"A={A} training={training} step {t}"
+        assert_bits(t2n(o), o2, what + " obs")
+        assert_bits(t2n(r), r2, what + " rewards")
+        assert_bits(t2n(d), d2, what + " dones")
+        assert_bits(t2n(env.cash), ref.cash, what + " cash")
+        assert_bits(t2n(env.margin), ref.margin, what + " margin")
+        assert_bits(t2n(env.env_indices), ref.env_idx, what + " env_idx")
+        assert ("returns" in i) == ("returns" in i2)
+        dones += int(d2.sum())
+    assert dones > N  # every env finished at least one episode
+
+
+def test_rebinding_mid_rollout_cannot_free_or_detach_the_kernels_storage(fe, fo):
+    """What VERDICT round 4 (weak #2) described: `env.cash = S * torch.ones(N, 1)` used to leave fe_env pointing at the OLD
+    tensor whose last Python reference had just been dropped -- the caching allocator could hand that block to the next
+    allocation and every later step() scribbled account state into it.  Now: rebind every public attribute mid-rollout,
+    drop all outside references, allocate decoys that would receive any freed block, keep stepping -- the decoys stay
+    untouched, the kernel still writes the storage the properties return, and the trajectory equals the oracle's with the
+    same state imposed."""
+    from finenvs_amd.data import synthetic
+
+    W, N, A = 8, 4096, 1
+    prices, day_id, _ = synthetic.synthetic_series(6, A, 40, 7)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    D = P.shape[0]
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, starting_balance=700.0)
+    ref = fo.OracleEnv(P, LR, W, num_envs=N, evaluate=True, starting_balance=700.0)
+    gen = torch.Generator().manual_seed(1)
+
+    def both_step(k):
+        for _ in range(k):
+            a = (torch.rand((N, A), generator=gen) * 2 - 1).float()
+            o, r, d, _ = env.step(a.to(env.device))
+            o2, r2, d2, _ = ref.step(a.numpy())
+            assert_bits(t2n(o), o2, "obs")
+            assert_bits(t2n(r), r2, "rewards")
+            assert_bits(t2n(d), d2, "dones")
+            assert_bits(t2n(env.cash), ref.cash, "cash")
+            assert_bits(t2n(env.margin), ref.margin, "margin")
+            assert_bits(t2n(env.long_shares), ref.long, "long")
+            assert_bits(t2n(env.short_shares), ref.short, "short")
+            assert_bits(t2n(env.env_spots[:, 0]), ref.spot0, "spot0")
+
+    env.reset()
+    both_step(12)
+    bound = {k: getattr(env, k).data_ptr() for k in ("cash", "margin", "long_shares", "short_shares", "env_indices", "episode_returns")}
+    # --- rebind everything, as a caller of the reference may (fresh tensors; some CPU, some GPU; reference shapes / dtypes)
+    S = env.starting_balance
+    new_idx = (torch.arange(N) * 5 + 2) % D
+    env.env_indices = new_idx.to(env.device)
+    env.env_spots = (torch.arange(0, W) + 3).repeat(N, 1)
+    env.env_pointers = torch.full((N,), 3, dtype=torch.int64)
+    env.cash = (S + 25.0) * torch.ones((N, 1), device=env.device)
+    env.long_shares = 2 * torch.ones((N, 1))
+    env.short_shares = torch.zeros((N, 1), dtype=torch.float64)  # (any dtype: stored as the reference ends up holding it)
+    env.margin = torch.zeros((N, 1))
+    env.terminated_episodes = torch.zeros((N,), dtype=torch.bool)
+    env.episode_returns = torch.zeros((N,))
+    ref.env_idx[:] = new_idx.numpy(); ref.spot0[:] = 3; ref.cash[:] = np.float32(S + 25.0); ref.long[:] = 2.0; ref.short[:] = 0.0
+    ref.margin[:] = 0.0; ref.terminated[:] = 0; ref.episode_returns[:] = 0; ref.n_terminated[0] = 0
+    gc.collect()
+    # --- decoys: whatever block an assignment might have released would be handed out again here
+    sentinel32, sentinel64 = 12345.5, -777.25
+    decoys = [torch.full((N, 1), sentinel32, device=env.device) for _ in range(24)]
+    decoys += [torch.full((N, 1), sentinel64, dtype=torch.float64, device=env.device) for _ in range(24)]
+    decoys += [torch.full((N,), 424242, dtype=torch.int64, device=env.device) for _ in range(24)]
+    assert {k: getattr(env, k).data_ptr() for k in bound} == bound  # the kernel's pointers are where they were
+    decoy_ptrs = {d.data_ptr() for d in decoys}
+    assert not (decoy_ptrs & set(bound.values()))
+    both_step(25)
+    torch.cuda.synchronize()
+    for d in decoys:
+        want = sentinel32 if d.dtype is torch.float32 else sentinel64 if d.dtype is torch.float64 else 424242
+        assert bool((d == want).all()), "a decoy allocation was written by the step kernel"
+    # in-place edits of what the getters return reach the kernel (the bound storage IS the public tensor)
+    env.cash[:7] = 5.0
+    ref.cash[:7] = 5.0
+    env.margin.zero_()
+    ref.margin[:] = 0.0
+    both_step(5)
+
+
+def test_public_state_setters_validate(fe, fo):
+    from finenvs_amd.data import synthetic
+
+    W, N = 8, 64
+    prices, day_id, _ = synthetic.synthetic_series(5, 1, 40, 3)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    D, L = P.shape[0], P.shape[1]
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True)
+    with pytest.raises(ValueError, match="expected 64 values"):
+        env.cash = torch.ones((N + 1, 1))
+    with pytest.raises(ValueError, match="follows env_indices"):
+        env.num_envs = N + 1
+    with pytest.raises(ValueError, match="day indices"):
+        env.env_indices = torch.full((N,), D)
+    with pytest.raises(ValueError, match="consecutive"):
+        env.env_spots = torch.zeros((N, W), dtype=torch.int64)
+    with pytest.raises(ValueError, match="out of range"):
+        env.env_spots = (torch.arange(0, W) + (L - W)).repeat(N, 1)
+    with pytest.raises(ValueError, match="derived"):
+        env.env_pointers = torch.ones((N,), dtype=torch.int64)
+    env.env_pointers = torch.zeros((N,), dtype=torch.int64)  # == env_spots[:, 0]: accepted
+    env.num_envs = N
+    # terminated_episodes: the reference's bool tensor (TSE:272-274); the count the kernel reports follows an assignment
+    env.terminated_episodes = torch.arange(N) % 2 == 0
+    assert int(env._counters[0]) == N // 2 and env.terminated_episodes.dtype is torch.bool
+    # a sharded env cannot be resized
+    sh = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, rank=0, world_size=2)
+    with pytest.raises(ValueError, match="sharded"):
+        sh.env_indices = torch.arange(N) % D
+    sh.env_indices = torch.arange(N // 2) % D  # same length: a plain copy
+
+
+def test_resize_invalidates_objects_that_hold_the_old_binding(fe, fo):
+    """A captured hipGraph, an EpisodeStats and a fused rollout hold pointers / sizes of the env as it was: after a resize
+    they refuse to run instead of writing through stale pointers."""
+    from finenvs_amd.data import synthetic
+    from finenvs_amd.rollout import FusedLinearRollout, GraphedRollout
+    from finenvs_amd.stats import EpisodeStats
+
+    W, N = 8, 256
+    prices, day_id, _ = synthetic.synthetic_series(5, 1, 40, 3)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    D = P.shape[0]
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, redraw="device", obs_buffers=2)
+    acts = [(torch.rand((N, 1), device=env.device) * 2 - 1) for _ in range(2)]
+    roll = GraphedRollout(env, lambda obs, k: acts[k % 2], 2)
+    roll.run()
+    stats = EpisodeStats(env)
+    fused = FusedLinearRollout(env, torch.zeros((W, 5), dtype=torch.float64), 0.1)
+    env.env_indices = torch.arange(2 * N) % D
+    assert env.num_envs == 2 * N and len(env._obs_ring) == 2 and env._obs_ring[0].shape[0] == 2 * N
+    with pytest.raises(RuntimeError, match="resized"):
+        roll.run()
+    with pytest.raises(RuntimeError, match="resized"):
+        stats.read()
+    with pytest.raises(RuntimeError, match="resized"):
+        fused.run(2)
+    stats.close()
+    # and a GraphedRollout captured on the f32 arithmetic refuses once the env has been promoted by f64 actions
+    roll = GraphedRollout(env, lambda obs, k: torch.zeros((2 * N, 1), device=env.device), 2)
+    roll.run()
+    env.step(torch.zeros((2 * N, 1), dtype=torch.float64, device=env.device))
+    assert env.shares_promoted
+    with pytest.raises(RuntimeError, match="float64 actions after this graph was captured"):
+        roll.run()
+
+
+def test_refused_float64_step_does_not_promote(fe, fo):
+    """A step() refused by argument validation must leave the env as it was (advisor, round 4): float64 actions together with
+    `actions_out` raise -- and the env keeps the f32 arithmetic and its f32 share tensors."""
+    from finenvs_amd.data import synthetic
+
+    W, N = 8, 32
+    prices, day_id, _ = synthetic.synthetic_series(5, 1, 40, 3)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True)
+    a64 = torch.zeros((N, 1), dtype=torch.float64, device=env.device)
+    with pytest.raises(ValueError, match="float32 copy"):
+        env.step(a64, actions_out=torch.empty((N, 1), device=env.device))
+    with pytest.raises(ValueError, match="rewards_out"):
+        env.step(a64, rewards_out=torch.empty((N,), device=env.device))
+    assert not env.shares_promoted and env.long_shares.dtype is torch.float32
+    env.step(a64)
+    assert env.shares_promoted and env.long_shares.dtype is torch.float64

@@ -6,10 +6,13 @@ import os, sys, torch, statistics
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import finenvs_amd
 from bench import CONFIGS, make_series
-for cfg in (2, 3):
+for cfg, f32obs in ((2, False), (2, True), (3, False)):
     name, N, A, W = CONFIGS[cfg]
+    name += " (f32 observations: the promoted path takes the unpipelined tile loop)" if f32obs else ""
     prices, day_id, _ = make_series(A)
-    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", seed=1, obs_buffers=2)
+    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", seed=1, obs_buffers=2,
+                                    obs_dtype=torch.float32 if f32obs else torch.float64)
+    info0 = env.launch_info()
     g = torch.Generator(device="cuda:0").manual_seed(7)
     a32 = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
     a64 = [x.double() for x in a32]
@@ -27,4 +30,5 @@ for cfg in (2, 3):
     t32 = run(a32)
     t64 = run(a64)          # promotes the env
     t32p = run(a32)         # f32 actions on the promoted env
+    print(f"   launch_info before / after the promotion: {info0} / {env.launch_info()}")
     print(f"{name}: f32 actions {t32:.2f} us/step | f64 actions (promoted) {t64:.2f} | f32 actions on the promoted env {t32p:.2f}")
