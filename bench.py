@@ -254,8 +254,11 @@ def pmc_child(args):
     g = torch.Generator(device="cuda:0").manual_seed(7)
     actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
     env.reset()
-    for i in range(16):
-        env.step(actions[i % 8])
+    rew = torch.empty((N,), dtype=torch.float64, device="cuda:0")
+    done = torch.empty((N,), dtype=torch.int32, device="cuda:0")
+    act = torch.empty((N, A), dtype=torch.float32, device="cuda:0")
+    for i in range(16):  # the timed loop's form of the step: trajectory outputs (+ the host flag with --redraw torch)
+        env.step(actions[i % 8], rewards_out=rew, dones_out=done, actions_out=act)
     torch.cuda.synchronize()
 
 
@@ -368,44 +371,61 @@ class Dist:
         return bool(t.item() > 0.5)
 
 
-def kernel_interval_ms(env, actions, k2: int, runs: int = 3, all_runs: bool = False):
-    """Average launch interval of the step kernel: k2 launches issued straight through the C ABI (fe_env_step_traj with
-    preallocated outputs -- the form of the kernel the timed loop launches --, no per-step Python work) so the queue never drains, bracketed by ONE pair of HIP events on the launch stream (torch's
-    current stream is the stream the C ABI launches on); the interval = kernel + the ~1.5 us launch boundary.  Uses the
-    env's own observation ring (keeps the HBM / MALL regime of the timed region).  Median of `runs` (or all of them)."""
-    from finenvs_amd import _lib as _fl
+class KernelTrain:
+    """Back-to-back launches of the step kernel straight through the C ABI -- the SAME entry point and FORM the timed loop's
+    env.step() dispatches to: fe_env_step_traj (FORM 1: trajectory outputs) or, when this env polls a host flag
+    (redraw='torch' on the rank that owns the evaluation env), fe_env_step_traj_notify (FORM 3) -- with preallocated outputs and
+    no per-step Python work, so the queue never drains; ONE pair of HIP events on the launch stream brackets the train
+    (torch's current stream is the stream the C ABI launches on).  interval = kernel + launch boundary.  Uses the env's own
+    observation ring (the HBM / MALL regime of the timed region).  The host flag is written, never read, inside a train: the
+    evaluation env simply keeps its day (a redraw is host work outside the kernel)."""
 
-    N, dev = env.num_envs, env._dev
-    stream = torch.cuda.current_stream().cuda_stream
-    obs_b = [t.data_ptr() for t in env._obs_ring]
-    nb = len(obs_b)
-    rew_b = torch.empty((N,), dtype=torch.float64, device=dev)
-    done_b = torch.empty((N,), dtype=torch.int32, device=dev)
-    # the same FORM of the kernel as the timed loop launches (its step writes agent.store's action copy too)
-    act_b = torch.empty((N, env.num_assets), dtype=torch.float32, device=dev)
-    aptr = [a.data_ptr() for a in actions]
-    fn, h = env._lib.fe_env_step_traj, env._handle_v
-    rp, dp, ap = rew_b.data_ptr(), done_b.data_ptr(), act_b.data_ptr()
-    out = []
-    for _ in range(runs):
+    def __init__(self, env, actions):
+        N, dev = env.num_envs, env._dev
+        self.env = env
+        self.obs = [t.data_ptr() for t in env._obs_ring]
+        self.rew = torch.empty((N,), dtype=torch.float64, device=dev)
+        self.done = torch.empty((N,), dtype=torch.int32, device=dev)
+        self.act = torch.empty((N, env.num_assets), dtype=torch.float32, device=dev)  # agent.store's action copy
+        self.aptr = [a.data_ptr() for a in actions]
+        self.notify = env._flag is not None and not env.evaluate
+        self.form = 3 if self.notify else 1
+
+    def run(self, k: int) -> float:
+        """ms per launch of one train of k launches."""
+        from finenvs_amd import _lib as _fl
+
+        env = self.env
+        stream = torch.cuda.current_stream().cuda_stream
+        h, rp, dp, ap, obs, aptr, nb = env._handle_v, self.rew.data_ptr(), self.done.data_ptr(), self.act.data_ptr(), self.obs, self.aptr, len(self.obs)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        rc = 0
+        if self.notify:
+            fn, flag, seq = env._lib.fe_env_step_traj_notify, env._flag, env._flag_seq
+            e0.record()
+            for i in range(k):
+                seq = (seq + 1) & 0x3FFFFFFFFFFFFFFF
+                rc |= fn(h, aptr[i % 8], obs[i % nb], rp, dp, ap, None, None, flag, seq, stream)
+            e1.record()
+            env._flag_seq = seq
+        else:
+            fn = env._lib.fe_env_step_traj
+            e0.record()
+            for i in range(k):
+                rc |= fn(h, aptr[i % 8], obs[i % nb], rp, dp, ap, None, None, stream)
+            e1.record()
         torch.cuda.synchronize()
-        e0.record()
-        for i in range(k2):
-            rc = fn(h, aptr[i % 8], obs_b[i % nb], rp, dp, ap, None, None, stream)
-        e1.record()
-        torch.cuda.synchronize()
-        _fl.check(rc)
-        out.append(e0.elapsed_time(e1) / k2)
-    return out if all_runs else statistics.median(out)
+        env._generation += k
+        if rc:
+            _fl.check(rc)
+        return e0.elapsed_time(e1) / k
 
 
-def launches_per_run(env, actions, steps: int) -> int:
-    """How many back-to-back launches one HIP-event pair brackets in kernel_interval_ms: at least `steps` and 20, and enough
-    for ~10 ms of GPU time (at most 400) -- a train of 20 launches of a 30 us kernel is dominated by its first launches, which
-    start on an idle GPU whose XCDs wake up staggered, and would overstate the launch interval by ~5 %."""
-    est_ms = kernel_interval_ms(env, actions, 8, runs=1)
-    return int(min(400, max(20, steps, round(10.0 / max(est_ms, 1e-6)))))
+def launches_per_train(est_step_ms: float, steps: int) -> int:
+    """Launches one HIP-event pair brackets: at least 40 (and `steps`), enough for ~10 ms of GPU time, at most 400 -- a short
+    train of a 30 us kernel is dominated by its first launches (they start on a GPU whose XCDs wake up staggered, DESIGN.md
+    section 5)."""
+    return int(min(400, max(40, steps, round(10.0 / max(est_step_ms, 1e-6)))))
 
 
 def auto_repeats(repeats: int, steps: int, est_step_s: float) -> int:
@@ -415,9 +435,10 @@ def auto_repeats(repeats: int, steps: int, est_step_s: float) -> int:
     return int(min(40, max(5, round(0.15 / max(steps * est_step_s, 1e-9)))))
 
 
-def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: int, with_cpu: bool):
+def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: int, with_cpu: bool, redraw: str = None):
     """Build the env of one BASELINE config on this rank, time it, tear it down.  Returns the result dict
-    (on every rank; only rank 0 prints)."""
+    (on every rank; only rank 0 prints).  `redraw`: the evaluation env's redraw mode (default: --redraw)."""
+    redraw = redraw or args.redraw
     import finenvs_amd
     from finenvs_amd import _lib as _fl
     from finenvs_amd.trajectory import TrajectoryBuffer
@@ -442,7 +463,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             time.sleep(0.5)
         env = finenvs_amd.TimeSeriesEnv(
             prices=prices, day_id=day_id, num_intervals=W, num_envs=n_per_gpu * world, rank=rank, world_size=world,
-            device_id=D.local_rank, redraw=args.redraw, seed=1234, obs_buffers=obs_buffers,
+            device_id=D.local_rank, redraw=redraw, seed=1234, obs_buffers=obs_buffers,
             obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
         N = env.num_envs
         g = torch.Generator(device=dev).manual_seed(7 + rank)
@@ -516,10 +537,15 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
 
     trace = os.environ.get("FE_BENCH_TRACE") == "1"  # stderr: where a timed block's wall time goes (host issue / drain / fence)
 
+    train = [None, 0]  # KernelTrain of this env (built once its launch rate is known), launches per train
+
     def timed_blocks(r):
         """r blocks of exactly `steps` steps, each bracketed by a full fence (drain + synchronize + barrier + synchronize) on
-        both sides, as the driver's contract says; the block's time is the MAX over ranks."""
-        out = []
+        both sides, as the driver's contract says; the block's time is the MAX over ranks.  Straight after each block's
+        closing fence ONE kernel train runs (KernelTrain: back-to-back C-ABI launches of the loop's own kernel form between
+        a pair of HIP events): block and train alternate, so `roofline.kernel_ms` and `ms_per_step` are medians over the
+        same stretch of time, on the same buffers, in the same clock regime.  Returns (block seconds, train ms per launch)."""
+        out, trains = [], []
         for _ in range(r):
             fence()
             t0 = time.perf_counter()
@@ -534,7 +560,9 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
                 t3 = time.perf_counter()
                 print(f"[trace] issue {(t1 - t0) * 1e6:8.1f} us  drain {(t2 - t1) * 1e6:8.1f} us  fence+max {(t3 - t2) * 1e6:8.1f} us  "
                       f"({steps} steps)", file=sys.stderr, flush=True)
-        return out
+            if train[0] is not None:
+                trains.append(train[0].run(train[1]))
+        return out, trains
 
     run_steps(warmup)
     fence()
@@ -543,6 +571,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     fence()
     est = D.max_over_ranks(time.perf_counter() - t0) / min(steps, 8)
     R = auto_repeats(repeats, steps, est)
+    if roll is None:
+        train[0], train[1] = KernelTrain(env, actions), launches_per_train(est * 1e3, steps)
     total_envs = env.global_num_envs if world > 1 else N
 
     def settle():
@@ -574,9 +604,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             fence()
             traj.clear()
             run_steps(T)  # one full chunk: the first timed block has something to gather
-        aa_blocks = timed_blocks(R)
-        k_aa = launches_per_run(env, actions, steps)
-        aa_kern = kernel_interval_ms(env, actions, k_aa, runs=3)
+        aa_blocks, aa_trains = timed_blocks(R)
+        aa_kern = statistics.median(aa_trains)
         ring_before = [t.data_ptr() for t in env._obs_ring]
         env.audition_ring(AUDITION_EXTRA, AUDITION_BUDGET)
         changed = [t.data_ptr() for t in env._obs_ring] != ring_before
@@ -590,7 +619,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
                         "what": "the same timed loop and fences as `value`, on the observation ring as the allocator handed it out "
                                 "(before the placement audition)"}
         if D.all_ok(not changed):
-            reuse_blocks = aa_blocks
+            reuse_blocks = (aa_blocks, aa_trains)
             as_allocated["same_run_as_value"] = True
         # warm the (possibly new) buffers: first touch, translations.  Unconditional and without collectives: the ranks
         # of an N > 1 run may keep different buffers, but must stay in step
@@ -609,11 +638,12 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         fence()
         traj.clear()
         run_steps(T)  # one full chunk: the first timed block has something to gather
-        legs["with_all_gather"] = reuse_blocks if reuse_blocks is not None else timed_blocks(R)
+        legs["with_all_gather"], kern = reuse_blocks if reuse_blocks is not None else timed_blocks(R)
         fence()
         gather[0] = False
         traj.clear()
-        legs["no_all_gather"] = timed_blocks(R)
+        settle()
+        legs["no_all_gather"], _ = timed_blocks(R)
         head = legs["with_all_gather"]
         # Gather-only leg: the all-gather of one filled chunk ALONE (issue + drain between fences, no env steps beside
         # it), so that "with / without all-gather" above can be decomposed: an exposed gather shows up as
@@ -634,15 +664,19 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         fence()
         traj.clear()
     else:
-        legs["single_gpu"] = reuse_blocks if reuse_blocks is not None else timed_blocks(R)
+        legs["single_gpu"], kern = reuse_blocks if reuse_blocks is not None else timed_blocks(R)
         head = legs["single_gpu"]
     block = statistics.median(head)
 
-    # Kernel duration for the roofline (kernel_interval_ms): launches issued straight through the C ABI, one pair of
-    # HIP events on the launch stream around them.
-    k2 = launches_per_run(env, actions, steps)
-    kern = kernel_interval_ms(env, actions, k2, runs=3, all_runs=True)
+    # Kernel duration for the roofline: the trains that alternated with the headline's timed blocks (timed_blocks).  --graph
+    # has no C-ABI train of its own (the graph replays the lean form): three trains of the full form after the blocks.
+    if not kern:
+        train[0], train[1] = KernelTrain(env, actions), launches_per_train(est * 1e3, steps)
+        settle()
+        kern = [train[0].run(train[1]) for _ in range(3)]
+    k2 = train[1]
     kern_ms = statistics.median(kern)
+    form = train[0].form
 
     Bh = hbm_bytes(W, A, obs_elem)
     Bs = survey_bytes(W, A) - (4 * W * 5 * A if args.obs_f32 else 0)
@@ -667,17 +701,21 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
-            # the instantiation kernel_interval_ms launches (fe_env_step_traj: the full form) -- the row to look up in
-            # profiles/*_kernel_stats.csv; the timed loop (env.step with trajectory slots) launches the same one, or with
-            # redraw='torch' its host-flag variant (FORM 3: same arithmetic, last tile first)
-            "kernel": step_kernel_name(W, A, args.obs_f32, 1),
-            "timed_loop_kernel": step_kernel_name(W, A, args.obs_f32, 0 if roll is not None else  # (--graph: plain env.step, the lean form)
-                                                  (3 if (args.redraw == "torch" and env._flag is not None) else 1)),
+            # the instantiation the trains AND the timed loop launch (the row to look up in profiles/*_kernel_stats.csv):
+            # env.step with trajectory slots = fe_env_step_traj (FORM 1), or -- redraw='torch' on the rank that owns the
+            # evaluation env -- its host-flag variant fe_env_step_traj_notify (FORM 3: same arithmetic, the evaluation env's
+            # tile first)
+            "kernel": step_kernel_name(W, A, args.obs_f32, form),
+            "timed_loop_kernel": step_kernel_name(W, A, args.obs_f32, 0 if roll is not None else form),  # (--graph: plain env.step, the lean form)
             "kernel_ms": kern_ms,
-            "kernel_ms_regime": "tight loop: back-to-back C-ABI launches, one HIP-event pair around the train (kernel + the ~1.5 us "
-                                "launch boundary); Python-paced launches of the timed loop run the same kernel 5 - 10 % longer "
-                                "(XCDs wake up staggered after every gap, DESIGN.md section 5)",
-            "kernel_ms_runs": kern, "kernel_launches_per_run": k2,
+            "kernel_ms_regime": "median of the trains that ALTERNATE with the timed blocks (block, train, block, train ...): "
+                                "back-to-back C-ABI launches of the loop's own kernel form, one HIP-event pair on the launch stream "
+                                "around each train (kernel + launch boundary), same observation ring, same clock regime as the blocks",
+            "kernel_ms_runs": kern if len(kern) <= 8 else [min(kern), statistics.median(kern), max(kern)],
+            "kernel_launches_per_run": k2,
+            # for tools/summarize_prof.py: how the LAST launches of this instantiation in the run are laid out
+            "kernel_train_layout": {"repeats": len(kern), "loop_launches_per_block": steps, "train_launches": k2,
+                                    "order": "block, train, block, train, ..."} if roll is None else None,
             # `achieved` counts only bytes that must cross HBM (observation write + state + outputs):
             "hbm_bytes_per_env_step": Bh, "units_per_launch": N,
             # the window re-read of the SURVEY 8(d) formula comes from L2 / Infinity Cache, reported apart:
@@ -781,18 +819,22 @@ def two_stream_leg(args, steps: int):
             "frac_of_8TBps": Bh * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches_per_run": 2 * k2}
 
 
-REDRAW_CONTRACT = ("eval_redraw='device' (the headline): the evaluation env's day redraws come from a Philox4x32-10 counter "
-                   "inside the step kernel -- THIS BUILD's contract (finenvs_amd/rng.py; the generator is pinned to Random123's published "
-                   "known-answer vectors and to the oracle's restatement, the day SEQUENCE has no counterpart in the reference), no host synchronisation.  eval_redraw='torch' (the class "
-                   "default, timed as `reference_semantics`): the reference's own stream -- one torch.randint on the global "
-                   "generator per finished evaluation episode, decided by a per-step host read of dones[-1] (TSE:504-513); the "
-                   "reference-generated golden fixtures pin this mode.")
+REDRAW_CONTRACT = ("eval_redraw='torch' (the class default AND the headline): the reference's own stream -- one torch.randint on the "
+                   "global generator per finished evaluation episode, decided by a per-step host read of dones[-1] (TSE:504-513; here a "
+                   "coherent host flag the kernel writes, fe_env_step_traj_notify, not a device-to-host copy); the reference-generated "
+                   "golden fixtures and its call log (rng_calls.npz) pin this mode.  eval_redraw='device' (timed as `device_redraw`, "
+                   "same block protocol): the redraws come from a Philox4x32-10 counter inside the step kernel -- THIS BUILD's contract "
+                   "(finenvs_amd/rng.py; the generator is pinned to Random123's known-answer vectors and to the oracle's restatement, "
+                   "the day SEQUENCE has no counterpart in the reference), no host synchronisation: what hipGraph capture and the fused "
+                   "rollouts need.")
 
 
-def reference_semantics_leg(args, steps: int, repeats: int = 5):
+def reference_semantics_leg(args, steps: int, repeats: int = 0):
     """What a drop-in caller of the reference's loop gets (examples/time_series/PPO_LSTM_training_SPY.py:22-30): the CLASS
     DEFAULTS -- fresh observation / reward / done tensors per step (obs_buffers=0), redraw='torch' with the reference's
-    per-step host read of the evaluation env's done flag -- on the headline workload (config 2).  Never part of `value`."""
+    per-step host read of the evaluation env's done flag -- on the headline workload (config 2), timed with the headline's
+    block protocol (R blocks of exactly `steps` steps between synchronising fences after SETTLE_MS of untimed steps, median
+    block).  Never part of `value`."""
     import finenvs_amd
 
     name, N, A, W = CONFIGS[2]
@@ -803,10 +845,19 @@ def reference_semantics_leg(args, steps: int, repeats: int = 5):
     g = torch.Generator(device="cuda:0").manual_seed(7)
     actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
     states = env.reset()
-    for i in range(20 + int(SETTLE_MS / 0.03)):  # warm-up + the clock transient after the idle period of construction (run_workload.settle)
+    for i in range(20):
+        states, _, _, _ = env.step(actions[i % 8])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(8):
+        states, _, _, _ = env.step(actions[i % 8])
+    torch.cuda.synchronize()
+    est = (time.perf_counter() - t0) / 8
+    R = auto_repeats(repeats, steps, est)
+    for i in range(int(SETTLE_MS * 1e-3 / est)):  # the clock transient after the idle period of construction (run_workload.settle)
         states, _, _, _ = env.step(actions[i % 8])
     blocks = []
-    for _ in range(repeats):
+    for _ in range(R):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for i in range(steps):
@@ -817,10 +868,188 @@ def reference_semantics_leg(args, steps: int, repeats: int = 5):
     del env, states
     torch.cuda.empty_cache()
     return {"workload": name, "what": "class defaults: obs_buffers=0 (fresh tensors per step), redraw='torch' (per-step host read, TSE:510), "
-                                      "f64 observations, eager env.step(actions) loop",
+                                      "f64 observations, eager env.step(actions) loop; the headline's block protocol",
             "value": N * steps / med, "unit": "env-steps/s", "ms_per_step": med / steps * 1e3,
             "ms_per_step_min": min(blocks) / steps * 1e3, "ms_per_step_max": max(blocks) / steps * 1e3, "steps": steps,
-            "blocks": repeats}
+            "blocks": R}
+
+
+STRONG_TOTAL_ENVS = 65536  # BASELINE.json's metric: "env-steps/sec at 64k envs, 1/2/4/8 MI355X" read as ONE 64k-env job
+
+
+def strong_scaling_leg(args, D: Dist, steps: int, warmup: int, world: int = None, rank: int = None):
+    """The STRONG-scaling reading of the metric: 65 536 envs IN TOTAL, sharded contiguously over the world (8 GPUs: 8 192 envs
+    per GPU ~ 5 us of HBM time per step -- launch-bound, where the fused / graphed forms earn their keep).  Two launch modes:
+    `eager` (env.step per step, --redraw's mode, trajectory slots written by the kernel) and `graph_k8` (rollout.GraphedRollout,
+    8 steps per hipGraph replay, redraw='device' as capture requires); with N > 1 each with and without the trajectory
+    all-gather (one packed chunk per `steps` eager steps resp. per 8-step replay, asynchronous, double-buffered).
+    `world` / `rank`: emulate one rank's shard of a larger world on THIS GPU without collectives (the N = 1 run's preview of
+    the per-GPU step time at 2 / 4 / 8 GPUs: the measured basis of DESIGN.md section 7's strong-scaling rows)."""
+    import finenvs_amd
+    from finenvs_amd.rollout import GraphedRollout
+    from finenvs_amd.trajectory import TrajectoryBuffer
+
+    emulated = world is not None
+    w = world if emulated else D.world
+    r = rank if emulated else D.rank
+    dev = D.dev
+    _, _, A, W = CONFIGS[2]
+    prices, day_id, _ = make_series(A)
+    gathering = D.multi and not emulated
+    K = 8
+    steps_g = (steps + K - 1) // K * K
+    out = {"total_envs": STRONG_TOTAL_ENVS, "world": w, "emulated_on_one_gpu": emulated}
+
+    def fence(trajs=()):
+        for t in trajs:
+            t.drain()
+        if D.dist is not None and not emulated:
+            if D.backend != "nccl":
+                torch.cuda.synchronize()
+            D.barrier()
+        torch.cuda.synchronize()
+
+    def blocks_of(run_block, n_steps, trajs=(), r_blocks=None):
+        run_block()
+        fence(trajs)
+        t0 = time.perf_counter()
+        run_block()
+        fence(trajs)
+        est = (time.perf_counter() - t0) / n_steps
+        est = est if emulated else D.max_over_ranks(est)
+        R = r_blocks or auto_repeats(args.repeats, n_steps, est)
+        for _ in range(int(min(4000, SETTLE_MS * 1e-3 / max(est, 1e-9)) / n_steps) + 1):  # settle (run_workload.settle)
+            run_block()
+        ts = []
+        for _ in range(R):
+            fence(trajs)
+            t0 = time.perf_counter()
+            run_block()
+            fence(trajs)
+            dt = time.perf_counter() - t0
+            ts.append(dt if emulated else D.max_over_ranks(dt))
+        med = statistics.median(ts)
+        return {"value": STRONG_TOTAL_ENVS * n_steps / med, "us_per_step": med / n_steps * 1e6, "us_per_step_min": min(ts) / n_steps * 1e6,
+                "us_per_step_max": max(ts) / n_steps * 1e6, "blocks": R, "steps_per_block": n_steps}
+
+    # ---- eager
+    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=STRONG_TOTAL_ENVS, rank=r, world_size=w,
+                                    device_id=D.local_rank, redraw=args.redraw, seed=1234, obs_buffers=2)
+    n = env.num_envs
+    out["envs_per_gpu"] = n
+    g = torch.Generator(device=dev).manual_seed(7 + r)
+    actions = [(torch.rand((n, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
+    traj = TrajectoryBuffer(steps, n, A, device=dev)
+    env.reset()
+    gather = [False]
+
+    def eager_block():
+        for i in range(steps):
+            if traj.full():
+                if gather[0]:
+                    traj.all_gather_async(defer=True)
+                else:
+                    traj.clear()
+            a, rw, d = traj.next_slot()
+            env.step(actions[i % 8], rewards_out=rw, dones_out=d, actions_out=a)
+            if i == 2:
+                traj.issue_deferred()
+
+    for _ in range(max(1, warmup // max(steps, 1))):
+        eager_block()
+    out["eager"] = {"no_all_gather": blocks_of(eager_block, steps, (traj,))}
+    kt = KernelTrain(env, actions)
+    out["eager"]["kernel_us"] = statistics.median(kt.run(400) for _ in range(3)) * 1e3
+    out["eager"]["launch"] = env.launch_info()
+    if gathering:
+        gather[0] = True
+        traj.clear()
+        eager_block()
+        out["eager"]["with_all_gather"] = blocks_of(eager_block, steps, (traj,))
+        gather[0] = False
+        fence((traj,))
+        out["eager"]["packed_bytes_per_rank_per_chunk"] = traj._nbytes
+    del env, traj, kt
+    # ---- hipGraph, K steps per replay (two graphs over two trajectory chunks: chunk i is gathered while graph 1 - i replays)
+    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=STRONG_TOTAL_ENVS, rank=r, world_size=w,
+                                    device_id=D.local_rank, redraw="device", seed=1234, obs_buffers=2)
+    trajs = [TrajectoryBuffer(K, n, A, device=dev) for _ in range(2)]
+    rolls = [GraphedRollout(env, lambda obs, k: actions[k % 8], K, trajectory=t) for t in trajs]
+    pending = [None, None]
+    gathered = [None, None]
+
+    def graph_block():
+        for j in range(steps_g // K):
+            i = j & 1
+            if pending[i] is not None:
+                pending[i].wait()  # (stream-level for RCCL) chunk i has left before graph i overwrites it
+                pending[i] = None
+            rolls[i].run()
+            if gather[0]:
+                if gathered[i] is None:
+                    gathered[i] = torch.empty((D.dist.get_world_size(), trajs[i]._nbytes), dtype=torch.uint8, device=dev)
+                pending[i] = D.dist.all_gather_into_tensor(gathered[i].view(-1), trajs[i]._packed, async_op=True)
+
+    def graph_fence_extra():
+        for i in (0, 1):
+            if pending[i] is not None:
+                pending[i].wait()
+                pending[i] = None
+
+    class _Drain:  # fence() drains these like a TrajectoryBuffer
+        drain = staticmethod(graph_fence_extra)
+
+    out["graph_k8"] = {"no_all_gather": blocks_of(graph_block, steps_g, (_Drain,))}
+    if gathering:
+        gather[0] = True
+        out["graph_k8"]["with_all_gather"] = blocks_of(graph_block, steps_g, (_Drain,))
+        gather[0] = False
+        fence((_Drain,))
+        out["graph_k8"]["packed_bytes_per_rank_per_chunk"] = trajs[0]._nbytes
+    del rolls, trajs, env, gathered
+    gc.collect()
+    torch.cuda.empty_cache()
+    return out
+
+
+def device_guard_check(D: Dist):
+    """N > 1 only: the paths a one-GPU box cannot reach.  (i) fe_env_device(env) == LOCAL_RANK on every rank; (ii) a step() issued
+    while ANOTHER device is current (the reference's `device_id` argument works without torch.cuda.set_device, TSE:28, 42;
+    csrc/fe_env.hip DeviceGuard) launches on the env's device, returns tensors there, leaves the caller's current device
+    unchanged, and computes what a step with the env's device current computes.  Returns a pass / fail record (never raises)."""
+    import finenvs_amd
+
+    rec = {"local_rank": D.local_rank, "devices_visible": torch.cuda.device_count()}
+    try:
+        _, _, A, W = CONFIGS[1]
+        prices, day_id, _ = make_series(A)
+        mk = lambda: finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=1024, evaluate=True,  # noqa: E731
+                                               device_id=D.local_rank)
+        env, twin = mk(), mk()
+        rec["env_device"] = int(env._lib.fe_env_device(env._handle))
+        ok = rec["env_device"] == D.local_rank
+        a = (torch.rand((1024, A), device=D.dev) * 2 - 1).float()
+        o0, r0, d0, _ = twin.step(a)
+        if rec["devices_visible"] > 1:
+            other = (D.local_rank + 1) % rec["devices_visible"]
+            with torch.cuda.device(other):
+                before = torch.cuda.current_device()
+                o1, r1, d1, _ = env.step(a)
+                after = torch.cuda.current_device()
+            rec.update(other_device=other, current_device_before=before, current_device_after=after,
+                       outputs_on=str(o1.device), current_device_restored=torch.cuda.current_device() == D.local_rank)
+            torch.cuda.synchronize(D.dev)
+            same = bool(torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1))
+            rec["same_result_as_with_own_device_current"] = same
+            ok = ok and before == other and after == other and str(o1.device) == D.dev and same and rec["current_device_restored"]
+        else:
+            rec["other_device"] = None
+            rec["note"] = "one device visible: the cross-device half needs the multi-GPU node"
+        rec["pass"] = bool(ok)
+    except Exception as exc:  # noqa: BLE001
+        rec["pass"] = False
+        rec["error"] = f"{type(exc).__name__}: {exc}"
+    return rec
 
 
 def fused_rollout_legs(args):
@@ -836,7 +1065,7 @@ def fused_rollout_legs(args):
     legs = []
     for form, W, K in (("linear_table", 64, 32), ("mlp_h64", 64, 32), ("lstm_h128", 4, 8), ("lstm_h1024", 4, 2)):
         try:
-            env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw=args.redraw,
+            env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device",  # (in-kernel redraws)
                                             seed=1234, obs_buffers=1)
             flop = 0.0
             if form == "linear_table":
@@ -895,7 +1124,9 @@ def main():
     ap.add_argument("--repeats", type=int, default=0, help="timed K-step blocks (0 = auto: ~0.15 s of timed work, 5..40)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs")
-    ap.add_argument("--redraw", default="device", choices=["device", "torch"])
+    ap.add_argument("--redraw", default="torch", choices=["torch", "device"],
+                    help="the evaluation env's day redraw: 'torch' = the reference's RNG stream and per-step host read (class default, "
+                         "pinned by the reference's fixtures); 'device' = in-kernel Philox (timed as the `device_redraw` leg by default)")
     ap.add_argument("--obs-f32", action="store_true", help="f32 observations (NOT the reference dtype; extra mode)")
     ap.add_argument("--graph", action="store_true", help="replay the 8-action ring as one hipGraph per 8 steps")
     ap.add_argument("--no-audition", action="store_true", help="take the observation ring as allocated (no placement audition)")
@@ -912,6 +1143,9 @@ def main():
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
 
+    if args.graph and args.redraw != "device":
+        print("bench.py --graph: hipGraph capture cannot contain the per-step host read of redraw='torch' -> redraw='device'", file=sys.stderr)
+        args.redraw = "device"
     D = Dist(args)
     head = run_workload(args.config, args, D, args.steps, args.warmup, args.repeats,
                         with_cpu=(not args.no_cpu and not D.multi))
@@ -944,11 +1178,41 @@ def main():
                 extras.append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
                 break
 
-    fused = refsem = two_streams = None
+    # the strong-scaling reading of the metric (64k envs IN TOTAL over the world) beside the weak one; at N = 1 also the
+    # per-GPU shard of a 2 / 4 / 8-GPU world emulated on this GPU (no collectives): the measured basis of DESIGN.md section 7
+    strong = guard = None
+    if not args.no_extra and not args.graph and not args.obs_f32 and args.config == 2:
+        try:
+            strong = strong_scaling_leg(args, D, args.steps, args.warmup)
+            if not D.multi:
+                strong["shard_preview"] = [strong_scaling_leg(args, D, args.steps, args.warmup, world=w_, rank=w_ - 1) for w_ in (2, 4, 8)]
+        except Exception as exc:  # noqa: BLE001
+            if D.multi:
+                raise  # (a rank alone in an exception handler would leave the others in a collective)
+            strong = {"error": f"{type(exc).__name__}: {exc}"}
+    if D.multi:
+        mine = device_guard_check(D)
+        recs = [None] * D.dist.get_world_size()
+        D.dist.all_gather_object(recs, mine)
+        guard = {"pass": all(bool(r_ and r_.get("pass")) for r_ in recs), "ranks": recs,
+                 "what": "fe_env_device(env) == LOCAL_RANK on every rank; a step() issued with ANOTHER device current launches on the "
+                         "env's device, leaves the caller's current device unchanged and equals the step of a twin env (TSE:28, 42; DeviceGuard)"}
+
+    fused = refsem = two_streams = devred = None
     if not D.multi and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
+        if args.redraw == "torch" and args.config == 2:
+            # the build's own redraw contract on the same workload, the same ring policy, the same block protocol
+            try:
+                dr = run_workload(2, args, D, args.steps, args.warmup, args.repeats, with_cpu=False, redraw="device")
+                devred = {k: dr.get(k) for k in ("workload", "value", "ms_per_step", "steps", "warmup", "settle_steps", "repeats", "as_allocated", "error")}
+                if "roofline" in dr:
+                    devred.update(kernel=dr["roofline"]["kernel"], kernel_ms=dr["roofline"]["kernel_ms"], frac=dr["roofline"]["frac"])
+                devred["what"] = "the headline workload with eval_redraw='device' (in-kernel Philox redraws, no host flag), same ring, fences and block protocol as `value`"
+            except Exception as exc:  # noqa: BLE001
+                devred = {"error": f"{type(exc).__name__}: {exc}"}
         fused = fused_rollout_legs(args)
         try:
-            refsem = reference_semantics_leg(args, max(args.steps, 200))
+            refsem = reference_semantics_leg(args, args.steps, args.repeats)
         except Exception as exc:  # noqa: BLE001
             refsem = {"error": f"{type(exc).__name__}: {exc}"}
         try:
@@ -980,17 +1244,22 @@ def main():
                                                        "why": f"{SETTLE_MS:g} ms of steps straight before each timed phase: after an idle period the GPU "
                                                               "runs the same kernel 15 - 25 % slower for ~10 ms (clock transient, "
                                                               "profiles/r04_microbench/idle_transient.txt)"},
-                       "timed_region": "median of R blocks of exactly `steps` steps, each between (drain + synchronize + barrier + synchronize) "
-                                       "fences, MAX over ranks per block.  A block of --steps 20 at 64k envs is ~0.6 ms: the idle-GPU start of "
-                                       "every block (staggered XCD wake-up), the closing fence (N > 1: one barrier, tens of microseconds) and "
-                                       "env.step's Python make `ms_per_step` ~2 - 3 % longer than `roofline.kernel_ms`, the launch interval of "
-                                       "long back-to-back trains"},
+                       "timed_region": f"STEADY STATE: beyond --warmup {head['warmup']}, {head['settle_steps']} untimed steps ({SETTLE_MS:g} ms of GPU time) "
+                                       "run straight before the timed phase, because after an idle period this pool's GPUs run the same kernel "
+                                       "15 - 25 % slower for ~10 ms and a rollout runs for minutes (untimed_steps_before_timing).  Then: median of R blocks of "
+                                       "exactly `steps` steps, each between (drain + synchronize + barrier + synchronize) fences, MAX over ranks "
+                                       "per block; after each block one train of back-to-back C-ABI launches of the same kernel form gives "
+                                       "`roofline.kernel_ms` (same ring, same clock regime).  A block of --steps 20 at 64k envs is ~0.6 ms: the "
+                                       "idle-GPU start of every block, the closing fence and env.step's Python make `ms_per_step` a few per cent "
+                                       "longer than `roofline.kernel_ms`"},
             # the un-auditioned regime beside the headline: same loop, same fences, the ring as the allocator handed it out
             "as_allocated": head["as_allocated"],
             "repeats": head["repeats"],
             "roofline": head["roofline"],
             "cpu_baseline": head.get("cpu_baseline"),
-            "multi_gpu": head.get("multi_gpu"),
+            "multi_gpu": (dict(head["multi_gpu"], strong=strong, device_guard=guard) if head.get("multi_gpu") else None),
+            "strong_scaling": strong,
+            "device_redraw": devred,
             "extra_configs": [{k: v for k, v in e.items() if k != "cpu_baseline"} for e in extras],
             "fused_rollouts": fused,
             "reference_semantics": refsem,

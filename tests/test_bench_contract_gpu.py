@@ -32,16 +32,66 @@ def test_bench_prints_one_json_line_with_the_contract_fields():
     # achieved = algorithmic HBM bytes per launch / the kernel's HIP-event launch interval
     assert abs(r["achieved"] - r["hbm_bytes_per_env_step"] * r["units_per_launch"] / (r["kernel_ms"] * 1e-3) / 1e9) / r["achieved"] < 1e-9
     assert r["hbm_bytes_per_env_step"] == 2680 and r["units_per_launch"] == 65536
-    assert r["kernel_ms"] <= d["ms_per_step"] * 1.05  # the kernel cannot take longer than the wall step (5 % timing slack)
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.01  # the kernel cannot take longer than the wall step (trains alternate with the blocks)
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "env-steps/s" and "sample" in c
     assert "redraw_contract" in d["config"]
-    assert r["kernel"] == "fe_env_kernel<double, 2, true, false, 1>"  # the instantiation the timed loop launches
+    # the headline runs the reference-pinned mode: redraw='torch', whose step is the host-flag form of the full kernel
+    assert d["config"]["eval_redraw"] == "torch"
+    assert r["kernel"] == r["timed_loop_kernel"] == "fe_env_kernel<double, 2, true, false, 3>"  # what loop AND trains launch
+    assert d["config"]["timed_region"].startswith("STEADY STATE")
+    lay = r["kernel_train_layout"]
+    assert lay["repeats"] >= 3 and lay["loop_launches_per_block"] == 20 and lay["train_launches"] >= 40
     # the un-auditioned regime is in the line too: same loop and fences on the ring as allocated
     aa = d["as_allocated"]
     assert aa["value"] > 0 and aa["kernel_ms"] > 0 and aa["blocks"] >= 3
     assert abs(aa["value"] - 65536 / (aa["ms_per_step"] * 1e-3)) / aa["value"] < 1e-6
     assert d["config"]["obs_ring_audition"]["candidates"] <= 2 + d["config"]["obs_ring_audition_bound"]["extra_candidates"]
+
+
+def test_default_driver_command_every_leg_kernel_below_step_and_both_scaling_readings():
+    """The driver's N = 1 command in full (`--steps 20 --warmup 5`): for the headline AND every extra_configs leg the kernel
+    interval is at most the wall step (1 % slack; VERDICT round 4 #4: config 3 once read 3.505 > 3.485 ms); the build's own redraw
+    contract is a leg timed with the same protocol; the strong-scaling reading (64k envs in total) is in the line beside the
+    weak one, with the per-GPU shard of a 2 / 4 / 8-GPU world measured on this GPU."""
+    env = dict(os.environ, FE_CPU_THREADS="4")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-pmc", "--no-cpu"],
+                         capture_output=True, text=True, timeout=1100, env=env, cwd=REPO)
+    d = _one_json_line(out)
+    assert d["config"]["eval_redraw"] == "torch" and d["scaling"] == "weak"
+    legs = [d] + d["extra_configs"]
+    assert [e["config"] for e in d["extra_configs"]] == [3, 4, 5]
+    for leg in legs:
+        assert "error" not in leg, leg.get("error")
+        r = leg["roofline"]
+        assert r["kernel_ms"] <= leg["ms_per_step"] * 1.01, (leg.get("workload", "headline"), r["kernel_ms"], leg["ms_per_step"])
+        assert 0.3 < r["frac"] < 1.0 and r["kernel"] == r["timed_loop_kernel"] and r["kernel"].endswith(", 3>")
+    dr = d["device_redraw"]
+    assert "error" not in dr and dr["steps"] == 20 and dr["kernel"].endswith(", 1>") and dr["kernel_ms"] <= dr["ms_per_step"] * 1.01
+    assert dr["value"] > 0.9 * d["value"]  # the two modes run the same arithmetic: within 10 % of each other either way
+    rs = d["reference_semantics"]
+    assert rs["steps"] == 20 and rs["blocks"] >= 5 and rs["value"] > 0
+    st = d["strong_scaling"]
+    assert "error" not in st and st["total_envs"] == 65536 and st["world"] == 1 and st["envs_per_gpu"] == 65536
+    for mode in ("eager", "graph_k8"):
+        assert st[mode]["no_all_gather"]["value"] > 0 and "with_all_gather" not in st[mode]
+    assert [p["world"] for p in st["shard_preview"]] == [2, 4, 8]
+    assert [p["envs_per_gpu"] for p in st["shard_preview"]] == [32768, 16384, 8192]
+    for p in st["shard_preview"]:
+        assert p["emulated_on_one_gpu"] and p["eager"]["kernel_us"] < p["eager"]["no_all_gather"]["us_per_step"] * 1.01
+        # fewer envs per GPU: a step gets shorter (how much shorter is the strong-scaling curve)
+        assert p["graph_k8"]["no_all_gather"]["us_per_step"] < st["graph_k8"]["no_all_gather"]["us_per_step"]
+
+
+def _check_strong_and_guard(m, ranks, envs_per_gpu):
+    st = m["strong"]
+    assert st["total_envs"] == 65536 and st["world"] == ranks and st["envs_per_gpu"] == envs_per_gpu and not st["emulated_on_one_gpu"]
+    for mode in ("eager", "graph_k8"):
+        assert st[mode]["no_all_gather"]["value"] > 0 and st[mode]["with_all_gather"]["value"] > 0
+        assert st[mode]["packed_bytes_per_rank_per_chunk"] == (20 if mode == "eager" else 8) * envs_per_gpu * 16
+    g = m["device_guard"]
+    assert g["pass"] is True and len(g["ranks"]) == ranks
+    assert all(r["env_device"] == r["local_rank"] for r in g["ranks"])
 
 
 def _one_json_line(out):
@@ -72,6 +122,7 @@ def test_bench_n_gt_1_code_path_over_rccl_with_one_rank():
     assert d["n_gpus"] == 1 and d["scaling"] == "weak" and d["cpu_baseline"] is None  # (the CPU leg belongs to the plain N = 1 line)
     assert d["multi_gpu"]["collective_backend"] == "nccl"
     _check_multi_gpu_object(d["multi_gpu"], 1)
+    _check_strong_and_guard(d["multi_gpu"], 1, 65536)
     assert "rccl" in d["multi_gpu"] and d["multi_gpu"]["rccl"] is not None
     # value is the with-all-gather leg
     assert abs(d["value"] - d["multi_gpu"]["value_with_all_gather"]) / d["value"] < 1e-9
@@ -100,6 +151,7 @@ def test_bench_two_ranks_through_torch_distributed_run():
     d = _one_json_line(out)
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     _check_multi_gpu_object(d["multi_gpu"], 2)
+    _check_strong_and_guard(d["multi_gpu"], 2, 32768)  # the strong-scaling leg: 64k envs in total over the two ranks
     assert d["multi_gpu"]["collective_backend"] == "gloo"
     # weak scaling: every rank owns the config's full env count; value counts all ranks' envs
     assert d["config"]["envs_per_gpu"] == 65536

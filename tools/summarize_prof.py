@@ -6,9 +6,10 @@ short summary.
     python tools/summarize_prof.py <tag> <config>        (PROF_F32=1 for the f32-observation run)
 
 Why the split: one bench.py run launches the step kernel from two places --
-  * TRAINS: kernel_interval_ms issues trains of back-to-back launches straight through the C ABI (no Python work between
+  * TRAINS: bench.KernelTrain issues trains of back-to-back launches straight through the C ABI (no Python work between
     them); this is what `roofline.kernel_ms` / `achieved` / `frac` are computed from.  They are the LAST
-    3 x `kernel_launches_per_run` launches of the instantiation in the run (bench.py's order of work);
+    3 x `kernel_launches_per_run` launches of the instantiation in the run (rounds 2 - 4), or -- round 5, `roofline.kernel_train_layout` --
+    one train after each timed block (block, train, block, train ...: the tail of the instantiation's launches);
   * LOOP: the timed loop's env.step() launches (and its warm-up), one per Python iteration with trajectory slots that
     move every step; when the host keeps ahead of the GPU they queue back to back too, but every fence leaves the GPU
     idle and the first launches after a gap find the XCDs waking up staggered (DESIGN.md section 5);
@@ -86,9 +87,20 @@ def main():
     if headline_kernel not in by_form:
         headline_kernel = max(by_form, key=lambda k: len(by_form[k]))
     n_train = 3 * int(r.get("kernel_launches_per_run", 0))
+    layout = r.get("kernel_train_layout")  # round 5: trains ALTERNATE with the timed blocks (block, train, block, train ...)
 
     def groups(name):
         d = by_form[name]
+        if name == headline_kernel and layout:
+            R, nb, nt = int(layout["repeats"]), int(layout["loop_launches_per_block"]), int(layout["train_launches"])
+            tail = R * (nb + nt)
+            if 0 < tail <= len(d):
+                head, t = d[:len(d) - tail], d[len(d) - tail:]
+                loop, trains = list(head), []
+                for i in range(R):
+                    loop += t[i * (nb + nt): i * (nb + nt) + nb]
+                    trains += t[i * (nb + nt) + nb: (i + 1) * (nb + nt)]
+                return {"loop": loop, "trains": trains}
         cut = len(d) - n_train if (name == headline_kernel and 0 < n_train < len(d)) else len(d)
         return {"loop": d[:cut], "trains": d[cut:]}
 
@@ -152,10 +164,13 @@ def main():
         f.write(f"command: `rocprofv3 --kernel-trace --stats --output-format csv -- python3 bench.py --config {cfg} --steps {bench['steps']} "
                 f"--warmup {bench['warmup']} --no-cpu --no-extra --no-pmc --no-audition --repeats 2{' --obs-f32' if bench['dtype'] == 'f32' else ''}` "
                 f"(+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes); `--no-audition`: every launch of the run writes the ring as allocated\n\n")
-        f.write(f"**The kernel the bench line times: `{headline_kernel}`** (`roofline.kernel`; FORM 1 = the full form, launched by the timed "
-                f"loop's `env.step(..., rewards_out, dones_out, actions_out)` and by `kernel_interval_ms`' `fe_env_step_traj` trains).\n\n")
+        form = headline_kernel.rstrip(">").split(",")[-1].strip()
+        entry = {"1": "FORM 1 = the full form, `fe_env_step_traj`", "3": "FORM 3 = the full form with the host flag of redraw='torch', `fe_env_step_traj_notify`"}.get(form, f"FORM {form}")
+        f.write(f"**The kernel the bench line times: `{headline_kernel}`** (`roofline.kernel`; {entry}: launched by the timed "
+                f"loop's `env.step(..., rewards_out, dones_out, actions_out)` and by the C-ABI trains that alternate with its blocks; "
+                f"eval_redraw = {bench['config'].get('eval_redraw')}).\n\n")
         f.write("| regime | calls | rocprof avg | median | min | max | HBM GB/s at avg | frac of 8 TB/s |\n|---|---|---|---|---|---|---|---|\n")
-        for label, s_ in (("TRAINS (kernel_interval_ms: back-to-back C-ABI launches; `roofline.kernel_ms` is measured here)", tight),
+        for label, s_ in (("TRAINS (bench.KernelTrain: back-to-back C-ABI launches after each timed block; `roofline.kernel_ms` is measured here)", tight),
                           (f"LOOP (timed loop + warm-up: Python-issued env.step, moving trajectory slots; {loop_gaps} launches after an idle gap)", paced)):
             if s_:
                 f.write(f"| {label} | {s_['calls']} | {s_['avg_ns']/1e3:.2f} us | {s_['median_ns']/1e3:.2f} us | {s_['min_ns']/1e3:.2f} us | "
