@@ -383,7 +383,6 @@ class KernelTrain:
     def __init__(self, env, actions):
         N, dev = env.num_envs, env._dev
         self.env = env
-        self.obs = [t.data_ptr() for t in env._obs_ring]
         self.rew = torch.empty((N,), dtype=torch.float64, device=dev)
         self.done = torch.empty((N,), dtype=torch.int32, device=dev)
         self.act = torch.empty((N, env.num_assets), dtype=torch.float32, device=dev)  # agent.store's action copy
@@ -397,7 +396,8 @@ class KernelTrain:
 
         env = self.env
         stream = torch.cuda.current_stream().cuda_stream
-        h, rp, dp, ap, obs, aptr, nb = env._handle_v, self.rew.data_ptr(), self.done.data_ptr(), self.act.data_ptr(), self.obs, self.aptr, len(self.obs)
+        obs = [t.data_ptr() for t in env._obs_ring]  # read per train: the placement audition may have replaced ring members
+        h, rp, dp, ap, aptr, nb = env._handle_v, self.rew.data_ptr(), self.done.data_ptr(), self.act.data_ptr(), self.aptr, len(obs)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         rc = 0
         if self.notify:

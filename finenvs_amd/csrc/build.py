@@ -45,7 +45,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     return LIB
 
 
-VARIANT_KNOBS = ("FE_HOIST_FIRST", "FE_F32_WAVES")  # the live tunables of fe_device_common.h
+VARIANT_KNOBS = ("FE_HOIST_FIRST", "FE_F32_WAVES", "FE_COLD_PARAMS")  # the live tunables of fe_device_common.h
 
 
 def build_variant(tag: str, defines: dict, verbose: bool = False) -> str:

@@ -129,6 +129,8 @@ struct Params {
     // fields above stay as they were
     double scale64, ms64;  // max_shares + 0.5 and max_shares in f64 (f64 actions)
     int32_t act_f64;       // this step's actions are f64 (TSE:298-302 in f64)
+    int32_t has_stats;     // run_ret != nullptr (set per launch): the resident flag in front of the statistics pointers, which
+                           // the step kernel reads from the kernarg segment at their use (fe_step_kernel.h, cold parameters)
 };
 
 // ---- Philox4x32-10, the redraw generator of redraw_mode 1 ----

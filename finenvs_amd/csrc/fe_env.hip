@@ -217,6 +217,7 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     p.act_store = act_store;
     p.host_flag = reinterpret_cast<unsigned long long *>(host_flag);
     p.flag_seq = flag_seq;
+    p.has_stats = p.run_ret != nullptr ? 1 : 0;
     void *args[] = {&p};
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");

@@ -15,7 +15,42 @@ namespace {
 constexpr int kLean = 0, kFull = 1, kNotify = 2, kFullNotify = 3;
 constexpr bool form_is_full(int form) { return form == kFull || form == kFullNotify; }
 constexpr bool form_notifies(int form) { return form == kNotify || form == kFullNotify; }
-// PROMO: the arithmetic of an env whose share tensors the reference has promoted to f64 (sleeve_step, fe_device_common.h).
+// COLD PARAMETERS.  Params is ~100 dwords and the compiler keeps all of it in SGPRs from kernel entry on: in the full forms
+// it then runs out of the 106 it has, spills 16-register tuples into VGPR lanes and re-reads WHOLE tuples (v_readlane x 16) to
+// use two registers of them -- the full + host-flag form (FORM 3, the step of redraw='torch' with trajectory outputs) carried
+// 553 v_readlane on the accounting path and ran 29.9 us where forms 1 and 2 run 28.5 (profiles/r05_microbench/form_ab.txt).
+// Everything only rare or mode-specific branches need (evaluate-mode bookkeeping, episode statistics, host flag, Philox
+// redraw, the evaluate-mode ticket) is therefore read FROM THE KERNARG SEGMENT AT ITS USE, behind a resident scalar flag
+// (p.evaluate, p.has_stats, n == p.eval_env):
+// `ColdFor<FORM, SINGLE>::of(p)` is the kernel's own argument block (its only argument, at offset 0 of the segment) behind an opaque pointer --
+// the empty asm keeps the compiler from hoisting the scalar loads back to the kernel's entry -- so each becomes an
+// s_load next to its use and occupies registers only there.
+#ifndef FE_COLD_PARAMS
+#define FE_COLD_PARAMS 1
+#endif
+// Only the full + host-flag form takes its cold parameters this way (FE_COLD_PARAMS 1): it is the one that spilled, and the
+// other forms keep the code they were measured with (with the cold reads in ALL forms: FORM 1 28.6 -> 28.85 us, forms 0 / 2
+// unchanged, FORM 3 29.9 -> 28.95 us; profiles/r05_microbench/form_ab.txt).
+template <bool LAUNDER>
+struct Cold;
+template <>
+struct Cold<true> {
+    typedef const __attribute__((address_space(4))) Params *Ptr;
+    static __device__ __forceinline__ Ptr of(const Params &) {
+        Ptr kp = (Ptr)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(kp));
+        return kp;
+    }
+};
+template <>
+struct Cold<false> {
+    typedef const Params *Ptr;
+    static __device__ __forceinline__ Ptr of(const Params &p) { return &p; }
+};
+// (... and only in the single-asset kernels: the multi-asset tile loop never re-read spilled tuples on a hot path, and with
+// the cold reads three of its FORM 3 instantiations started to use 36 bytes of scratch.)
+template <int FORM, bool SINGLE>
+using ColdFor = Cold<(FE_COLD_PARAMS != 0) && FORM == 3 && SINGLE>;
 template <bool PROMO>
 using ActionT = typename std::conditional<PROMO, double, float>::type;
 template <bool SINGLE, int FORM, bool PROMO = false>
@@ -50,6 +85,8 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
             l.src[e] = (in.idx * L + s0c) * rs;
         }
         if constexpr (form_is_full(FORM)) {
+            // (the trajectory outputs are written every step when they are on: their pointers stay resident -- read at their
+            // use, the scalar loads' latency landed on every tile's accounting chain: FORM 1 28.6 -> 29.3 us)
             if (p.desc_src) {  // the returned observation as descriptors, 8 + 8A bytes per env (a trajectory's `states`)
                 p.desc_pos[sl] = s.pos_obs;
                 if (a == 0) p.desc_src[n] = l.src[e];
@@ -86,21 +123,26 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
         if (any) {
             s0 = 0;  // window rewinds to rows 0..W-1, TSE:514-521
             if (!p.evaluate && p.redraw_mode == 1 && n == p.eval_env) {  // TSE:504-513
-                unsigned long long ctr = p.counters[1];
-                p.env_idx[n] = (int64_t)(((uint64_t)philox_u32(p.seed, ctr) * (uint64_t)p.D) >> 32);
-                p.counters[1] = ctr + 1;
+                const typename ColdFor<FORM, SINGLE>::Ptr c = ColdFor<FORM, SINGLE>::of(p);
+                unsigned long long *const counters = c->counters;
+                unsigned long long ctr = counters[1];
+                p.env_idx[n] = (int64_t)(((uint64_t)philox_u32(c->seed, ctr) * (uint64_t)c->D) >> 32);
+                counters[1] = ctr + 1;
             }
         }
         p.spot0[n] = s0;
         if constexpr (form_is_full(FORM)) {
             if (p.evaluate) {  // TSE:523-536
-                const bool term = p.terminated[n] != 0;
+                const typename ColdFor<FORM, SINGLE>::Ptr c = ColdFor<FORM, SINGLE>::of(p);
+                uint8_t *const terminated = c->terminated;
+                float *const ep_ret = c->ep_ret;
+                const bool term = terminated[n] != 0;
                 if (term) rew = 0.0;
                 if (any && !term) {
-                    p.terminated[n] = 1;
-                    atomicAdd(&p.counters[0], 1ull);
+                    terminated[n] = 1;
+                    atomicAdd(&c->counters[0], 1ull);
                 }
-                p.ep_ret[n] = (float)((double)p.ep_ret[n] + rew);
+                ep_ret[n] = (float)((double)ep_ret[n] + rew);
             }
         }
         rew_out[n] = rew;
@@ -108,30 +150,35 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
         if constexpr (form_notifies(FORM)) {
             // fe_env_step_notify: the host polls this instead of copying dones back after the launch (TSE:510); a relaxed
             // system-scope store -- the host reads nothing else of this launch through it
-            if (n == p.eval_env)
-                __hip_atomic_store(p.host_flag, (p.flag_seq << 1) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (n == p.eval_env) {
+                const typename ColdFor<FORM, SINGLE>::Ptr c = ColdFor<FORM, SINGLE>::of(p);
+                __hip_atomic_store(c->host_flag, (c->flag_seq << 1) | (any ? 1ull : 0ull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
         if constexpr (form_is_full(FORM)) {
-            if (p.run_ret) {  // PPO_agent.py:120-132 without its per-step host sync
-                float cr = (float)((double)p.run_ret[n] + rew);
+            if (p.has_stats) {  // PPO_agent.py:120-132 without its per-step host sync
+                const typename ColdFor<FORM, SINGLE>::Ptr c = ColdFor<FORM, SINGLE>::of(p);
+                float *const run_ret = c->run_ret;
+                float cr = (float)((double)run_ret[n] + rew);
                 if (any) {
                     if (n == p.eval_env) {
-                        p.stat_eval[0] = cr;
-                        p.stat_eval[1] += 1.0f;
+                        float *const stat_eval = c->stat_eval;
+                        stat_eval[0] = cr;
+                        stat_eval[1] += 1.0f;
                     } else {
                         // per-env partial sums: env n's slots have ONE writer (the lane that owns env n; launches are
                         // stream-ordered), so what they add up to does not depend on the tile walk, the launch geometry
                         // or the form of the kernel; fe_env_stats_reduce adds the envs up in a fixed order.  The adds
                         // are issued as no-return memory atomics only so that the old values never occupy registers
                         // (as plain read-modify-writes they cost the f32 notify form a VGPR spill).
-                        double *acc = p.stat_acc + 3 * n;  // (N, 3): one address, three immediate offsets
+                        double *acc = c->stat_acc + 3 * n;  // (N, 3): one address, three immediate offsets
                         atomicAdd(acc, 1.0);
                         atomicAdd(acc + 1, (double)cr);
                         atomicAdd(acc + 2, (double)cr * (double)cr);
                     }
                     cr = 0.0f;
                 }
-                p.run_ret[n] = cr;
+                run_ret[n] = cr;
             }
         }
     }
@@ -518,11 +565,13 @@ __device__ __forceinline__ void env_kernel_body(const Params &p) {
             __threadfence();   // this thread's counter atomics are visible device-wide ...
             __syncthreads();   // ... and so are those of the whole workgroup
             if (tid == 0) {
-                const unsigned done = __hip_atomic_fetch_add(p.ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+                const typename ColdFor<FORM, SINGLE>::Ptr c = ColdFor<FORM, SINGLE>::of(p);
+                unsigned int *const ticket = c->ticket;
+                const unsigned done = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
                 if (done == gridDim.x - 1) {
-                    __hip_atomic_store(p.ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-                    const unsigned long long cnt = __hip_atomic_load(&p.counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    __hip_atomic_store(p.host_flag, (p.flag_seq << 32) | (cnt & 0xffffffffull), __ATOMIC_RELAXED,
+                    __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+                    const unsigned long long cnt = __hip_atomic_load(&c->counters[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(c->host_flag, (c->flag_seq << 32) | (cnt & 0xffffffffull), __ATOMIC_RELAXED,
                                        __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }

@@ -391,18 +391,26 @@ class TimeSeriesEnv:
             self.obs_audition = {"candidates": len(cands), "us": [], "kept": list(range(len(cands))), "budget_bytes": budget}
             return
         st = self._stream()
-        times = []
-        for buf in cands:
-            best = float("inf")
-            for rep in range(4):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+
+        def train(buf, k):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(k):
                 _lib.check(self._lib.fe_env_reset_obs(self._handle, buf.data_ptr(), st))
-                e1.record()
-                e1.synchronize()
-                if rep:  # the first launch warms the tables
-                    best = min(best, e0.elapsed_time(e1) * 1e3)
-            times.append(best)
+            e1.record()
+            e1.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / k
+
+        # Measured as the step is: trains of back-to-back renders (~2 ms each) after ~20 ms of settling launches (the box's
+        # clock transient after an idle period is 15 - 25 %, more than the differences looked for), candidates interleaved
+        # over three rounds, median per candidate.  (Round 4 timed single launches between host synchronisations: at 64k
+        # envs it swapped ring members on noise -- twice out of two runs the "faster" ring was 1 % slower.)
+        train(cands[0], 2)
+        est_us = train(cands[0], 2)
+        k = int(max(2, min(32, 2000.0 / max(est_us, 1e-3))))
+        train(cands[0], int(max(2, min(1000, 20000.0 / max(est_us, 1e-3)))))
+        rounds = [[train(buf, k) for buf in cands] for _ in range(3)]
+        times = [sorted(r[i] for r in rounds)[1] for i in range(len(cands))]
         # a candidate replaces the slowest ring member only if it is faster by more than `min_gain`: at 64k envs all
         # candidates lie within 2 % of each other and a swap on noise made a driver-like run 2.5 % SLOWER (round 4)
         ring = list(range(self.obs_buffers))

@@ -1,0 +1,62 @@
+"""GPU box: the four FORMs of the step kernel (0 lean, 1 full, 2 lean + host flag, 3 full + host flag) on ONE env and ONE
+observation ring, trains of back-to-back C-ABI launches, interleaved rounds (config 2: 64k envs x W64, f64 observations).
+
+    python tools/form_ab.py [rounds]
+"""
+import os, statistics, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import finenvs_amd
+from bench import CONFIGS, make_series
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
+name, N, A, W = CONFIGS[2]
+prices, day_id, _ = make_series(A)
+from finenvs_amd import _lib
+variant = os.environ.get("FORM_AB_LIB")  # an experiment build (finenvs_amd.csrc.build.build_variant), by name
+native = _lib.load(os.path.join(os.path.dirname(_lib.LIB_PATH), "variants", f"libfinenvs_amd.{variant}.so")) if variant else None
+print("library:", variant or "product")
+env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="torch", seed=1, obs_buffers=2, _native=native)
+g = torch.Generator(device="cuda:0").manual_seed(7)
+acts = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
+rew = torch.empty((N,), dtype=torch.float64, device="cuda:0")
+done = torch.empty((N,), dtype=torch.int32, device="cuda:0")
+acopy = torch.empty((N, A), dtype=torch.float32, device="cuda:0")
+L, h, st = env._lib, env._handle_v, torch.cuda.current_stream().cuda_stream
+obs = [t.data_ptr() for t in env._obs_ring]
+ap = [a.data_ptr() for a in acts]
+seq = [0]
+
+
+def launch(form, i):
+    if form == 0:
+        return L.fe_env_step(h, ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr(), st)
+    if form == 1:
+        return L.fe_env_step_traj(h, ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr(), acopy.data_ptr(), None, None, st)
+    seq[0] += 1
+    if form == 2:
+        return L.fe_env_step_notify(h, ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr(), env._flag, seq[0], st)
+    return L.fe_env_step_traj_notify(h, ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr(), acopy.data_ptr(), None, None, env._flag, seq[0], st)
+
+
+def train(form, k=400):
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    rc = 0
+    for i in range(k):
+        rc |= launch(form, i)
+    e1.record()
+    torch.cuda.synchronize()
+    assert rc == 0
+    return e0.elapsed_time(e1) / k * 1e3
+
+
+for f in range(4):
+    train(f, 800)  # settle
+res = {f: [] for f in range(4)}
+for r in range(rounds):
+    for f in ((0, 1, 2, 3) if r % 2 == 0 else (3, 2, 1, 0)):
+        res[f].append(train(f))
+for f in range(4):
+    v = res[f]
+    print(f"FORM {f}: median {statistics.median(v):.2f} us  min {min(v):.2f}  max {max(v):.2f}   {['%.2f' % x for x in v]}")
