@@ -1204,7 +1204,7 @@ def main():
             # the build's own redraw contract on the same workload, the same ring policy, the same block protocol
             try:
                 dr = run_workload(2, args, D, args.steps, args.warmup, args.repeats, with_cpu=False, redraw="device")
-                devred = {k: dr.get(k) for k in ("workload", "value", "ms_per_step", "steps", "warmup", "settle_steps", "repeats", "as_allocated", "error")}
+                devred = {k: dr[k] for k in ("workload", "value", "ms_per_step", "steps", "warmup", "settle_steps", "repeats", "as_allocated", "error") if k in dr}
                 if "roofline" in dr:
                     devred.update(kernel=dr["roofline"]["kernel"], kernel_ms=dr["roofline"]["kernel_ms"], frac=dr["roofline"]["frac"])
                 devred["what"] = "the headline workload with eval_redraw='device' (in-kernel Philox redraws, no host flag), same ring, fences and block protocol as `value`"
