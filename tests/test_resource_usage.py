@@ -3,7 +3,7 @@
 hipcc reports registers and scratch per kernel (-Rpass-analysis=kernel-resource-usage).  A streaming kernel that
 spills keeps part of its software pipeline in memory behind the very store stream it is trying to feed; round 2's
 f32 single-asset step kernels did (40 - 212 bytes per lane) while a comment claimed otherwise.  The table of this
-build is committed as profiles/r04_resource_usage.txt (tools/resource_usage.py --out ...).
+build is committed as profiles/r05_resource_usage.txt (tools/resource_usage.py --out ...).
 """
 import os
 import re
@@ -71,7 +71,7 @@ def test_lean_step_kernel_has_fewer_scalar_spills_than_the_full_one(table):
 
 
 def test_committed_table_matches_this_build(table):
-    path = os.path.join(ROOT, "profiles", "r04_resource_usage.txt")
+    path = os.path.join(ROOT, "profiles", "r05_resource_usage.txt")
     text = open(path).read()
     for r in table:
         if r["name"].startswith(("fe_env_kernel", "fe_render_kernel")):
