@@ -375,7 +375,9 @@ __device__ __forceinline__ void stream_tile(const Params &p, const TileLds &l, O
 // the grid is a multiple of 8, so t % 8 -- the XCD -- is stable per workgroup and envs mapped n mod D keep each XCD's
 // L2 on the same days).  XCD-blocked and scrambled orders were measured slower (profiles/r02_microbench/ab_xcd_blocked.txt).
 // `last_first` (fe_env_step_notify): the same walk from the other end, so that the tile holding the evaluation env --
-// the last env -- is the first tile of workgroup 0.
+// the last env -- is the first tile of workgroup 0.  (An ascending walk with only that tile moved to the front measures the
+// same, and so does a flag word in device memory: the 0.2 us the notify forms cost is code shape, not the walk or the PCIe store;
+// profiles/r05_microbench/form_ab.txt.)
 __device__ __forceinline__ int64_t tile_at(const Params &p, int64_t k, bool last_first = false) {
     const int64_t t = blockIdx.x + k * (int64_t)gridDim.x;
     if (t >= p.num_tiles) return p.num_tiles;
