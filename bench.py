@@ -54,6 +54,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 TRAJ_T = 16             # trajectory slots on one GPU (no exchange)
 AUDITION_EXTRA = 10     # ring audition: at most this many candidate buffers beyond the ring's own ...
 AUDITION_BUDGET = 48 << 30  # ... and at most this many bytes of them (config 2: 10 x 168 MB; config 3: 2 x 20 GB; configs 4 / 5: none)
+WATCHDOG_S = float(os.environ.get("FE_BENCH_WATCHDOG_S", "300"))  # N > 1: seconds the strong-scaling leg + DeviceGuard check may take before every rank gives up on them
 TRAJ_BUDGET = 48e9      # bytes of trajectory chunks + gathered copies a rank may hold (N > 1)
 SETTLE_MS = 20.0        # untimed steps before every timed phase: the box's clock transient after an idle period (run_workload.settle)
 # the reference's own PyTorch-CPU path, measured in the build container
@@ -1178,50 +1179,12 @@ def main():
                 extras.append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
                 break
 
-    # the strong-scaling reading of the metric (64k envs IN TOTAL over the world) beside the weak one; at N = 1 also the
-    # per-GPU shard of a 2 / 4 / 8-GPU world emulated on this GPU (no collectives): the measured basis of DESIGN.md section 7
-    strong = guard = None
-    if not args.no_extra and not args.graph and not args.obs_f32 and args.config == 2:
-        try:
-            strong = strong_scaling_leg(args, D, args.steps, args.warmup)
-            if not D.multi:
-                strong["shard_preview"] = [strong_scaling_leg(args, D, args.steps, args.warmup, world=w_, rank=w_ - 1) for w_ in (2, 4, 8)]
-        except Exception as exc:  # noqa: BLE001
-            if D.multi:
-                raise  # (a rank alone in an exception handler would leave the others in a collective)
-            strong = {"error": f"{type(exc).__name__}: {exc}"}
-    if D.multi:
-        mine = device_guard_check(D)
-        recs = [None] * D.dist.get_world_size()
-        D.dist.all_gather_object(recs, mine)
-        guard = {"pass": all(bool(r_ and r_.get("pass")) for r_ in recs), "ranks": recs,
-                 "what": "fe_env_device(env) == LOCAL_RANK on every rank; a step() issued with ANOTHER device current launches on the "
-                         "env's device, leaves the caller's current device unchanged and equals the step of a twin env (TSE:28, 42; DeviceGuard)"}
+    late = {}  # legs measured after the headline and extra_configs: build_line() reads what is there
 
-    fused = refsem = two_streams = devred = None
-    if not D.multi and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
-        if args.redraw == "torch" and args.config == 2:
-            # the build's own redraw contract on the same workload, the same ring policy, the same block protocol
-            try:
-                dr = run_workload(2, args, D, args.steps, args.warmup, args.repeats, with_cpu=False, redraw="device")
-                devred = {k: dr[k] for k in ("workload", "value", "ms_per_step", "steps", "warmup", "settle_steps", "repeats", "as_allocated", "error") if k in dr}
-                if "roofline" in dr:
-                    devred.update(kernel=dr["roofline"]["kernel"], kernel_ms=dr["roofline"]["kernel_ms"], frac=dr["roofline"]["frac"])
-                devred["what"] = "the headline workload with eval_redraw='device' (in-kernel Philox redraws, no host flag), same ring, fences and block protocol as `value`"
-            except Exception as exc:  # noqa: BLE001
-                devred = {"error": f"{type(exc).__name__}: {exc}"}
-        fused = fused_rollout_legs(args)
-        try:
-            refsem = reference_semantics_leg(args, args.steps, args.repeats)
-        except Exception as exc:  # noqa: BLE001
-            refsem = {"error": f"{type(exc).__name__}: {exc}"}
-        try:
-            two_streams = two_stream_leg(args, args.steps)
-        except Exception as exc:  # noqa: BLE001
-            two_streams = {"error": f"{type(exc).__name__}: {exc}"}
-
-    if D.rank == 0:
-        out = {
+    def build_line():
+        strong, guard = late.get("strong"), late.get("guard")
+        fused, refsem, two_streams, devred = (late.get(k) for k in ("fused", "refsem", "two_streams", "devred"))
+        return {
             "metric": "env-steps/sec",
             "value": head["value"],
             "unit": "env-steps/s",
@@ -1265,8 +1228,81 @@ def main():
             "reference_semantics": refsem,
             "two_streams": two_streams,
         }
-    else:
-        out = None
+
+    # the strong-scaling reading of the metric (64k envs IN TOTAL over the world) beside the weak one; at N = 1 also the
+    # per-GPU shard of a 2 / 4 / 8-GPU world emulated on this GPU (no collectives): the measured basis of DESIGN.md section 7
+    strong = guard = None
+    want_strong = not args.no_extra and not args.graph and not args.obs_f32 and args.config == 2
+    watchdog = None
+    if D.multi:
+        # The strong-scaling leg and the DeviceGuard check have never run with more than one RCCL rank before the driver's
+        # scaling bench.  They must not be able to cost the run its line: if they are not through after WATCHDOG_S, EVERY
+        # rank gives up at about the same time -- rank 0 prints the line it has (headline + extra_configs, the unfinished
+        # legs marked) and all ranks leave with exit code 0 without waiting for a collective that will not come.
+        import threading
+
+        def give_up():
+            late.setdefault("strong", {"error": f"not finished after {WATCHDOG_S:g} s (watchdog): leg abandoned"})
+            late.setdefault("guard", {"pass": False, "error": f"not finished after {WATCHDOG_S:g} s (watchdog)"})
+            if D.rank == 0:
+                sys.stderr.flush()
+                print(json.dumps(build_line()), file=result_out, flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(WATCHDOG_S, give_up)
+        watchdog.daemon = True
+    if want_strong:
+        if watchdog is not None:
+            watchdog.start()
+        try:
+            if os.environ.get("FE_BENCH_HANG_STRONG") == "1":  # rehearsal of the watchdog (tests only)
+                time.sleep(1e6)
+            strong = strong_scaling_leg(args, D, args.steps, args.warmup)
+            if not D.multi:
+                strong["shard_preview"] = [strong_scaling_leg(args, D, args.steps, args.warmup, world=w_, rank=w_ - 1) for w_ in (2, 4, 8)]
+        except Exception as exc:  # noqa: BLE001  (the same code runs on every rank: an exception here is raised on all of them)
+            strong = {"error": f"{type(exc).__name__}: {exc}"}
+        late["strong"] = strong
+    if D.multi:
+        if watchdog is not None and not watchdog.is_alive():
+            watchdog.start()
+        try:
+            mine = device_guard_check(D)
+            recs = [None] * D.dist.get_world_size()
+            D.dist.all_gather_object(recs, mine)
+            guard = {"pass": all(bool(r_ and r_.get("pass")) for r_ in recs), "ranks": recs,
+                     "what": "fe_env_device(env) == LOCAL_RANK on every rank; a step() issued with ANOTHER device current launches on the "
+                             "env's device, leaves the caller's current device unchanged and equals the step of a twin env (TSE:28, 42; DeviceGuard)"}
+        except Exception as exc:  # noqa: BLE001
+            guard = {"pass": False, "error": f"{type(exc).__name__}: {exc}"}
+        late["guard"] = guard
+        if watchdog is not None:
+            watchdog.cancel()
+
+    fused = refsem = two_streams = devred = None
+    if not D.multi and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
+        if args.redraw == "torch" and args.config == 2:
+            # the build's own redraw contract on the same workload, the same ring policy, the same block protocol
+            try:
+                dr = run_workload(2, args, D, args.steps, args.warmup, args.repeats, with_cpu=False, redraw="device")
+                devred = {k: dr[k] for k in ("workload", "value", "ms_per_step", "steps", "warmup", "settle_steps", "repeats", "as_allocated", "error") if k in dr}
+                if "roofline" in dr:
+                    devred.update(kernel=dr["roofline"]["kernel"], kernel_ms=dr["roofline"]["kernel_ms"], frac=dr["roofline"]["frac"])
+                devred["what"] = "the headline workload with eval_redraw='device' (in-kernel Philox redraws, no host flag), same ring, fences and block protocol as `value`"
+            except Exception as exc:  # noqa: BLE001
+                devred = {"error": f"{type(exc).__name__}: {exc}"}
+        fused = fused_rollout_legs(args)
+        try:
+            refsem = reference_semantics_leg(args, args.steps, args.repeats)
+        except Exception as exc:  # noqa: BLE001
+            refsem = {"error": f"{type(exc).__name__}: {exc}"}
+        try:
+            two_streams = two_stream_leg(args, args.steps)
+        except Exception as exc:  # noqa: BLE001
+            two_streams = {"error": f"{type(exc).__name__}: {exc}"}
+    late.update(fused=fused, refsem=refsem, two_streams=two_streams, devred=devred)
+
+    out = build_line() if D.rank == 0 else None
     if D.dist is not None:
         D.barrier()
         D.dist.destroy_process_group()

@@ -137,6 +137,19 @@ def test_bench_n_gt_1_code_path_over_rccl_with_one_rank():
     assert 0.3 < c5["roofline"]["frac"] < 1.0
 
 
+def test_watchdog_prints_the_line_if_the_new_multi_gpu_legs_hang():
+    """The strong-scaling leg and the DeviceGuard check run with more than one RCCL rank for the first time on the driver's node.
+    If they hang there (a collective that never completes), every rank gives up after WATCHDOG_S and rank 0 still prints the
+    line with the headline -- rehearsed here with a leg that sleeps forever and a 5 s watchdog (RCCL world 1)."""
+    env = dict(os.environ, FE_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29545", FE_BENCH_NO_EXTRA="1",
+               FE_BENCH_WATCHDOG_S="5", FE_BENCH_HANG_STRONG="1")
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "1", "--steps", "20", "--warmup", "5", "--no-pmc"],
+                         capture_output=True, text=True, timeout=600, env=env, cwd=REPO)
+    d = _one_json_line(out)
+    assert d["value"] > 0 and d["multi_gpu"]["value_with_all_gather"] > 0
+    assert "watchdog" in d["multi_gpu"]["strong"]["error"] and d["multi_gpu"]["device_guard"]["pass"] is False
+
+
 def test_bench_two_ranks_through_torch_distributed_run():
     """The driver's launch line for N = 2 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr
     127.0.0.1 ... bench.py --gpus 2 ...`) on a one-GPU box: both ranks on device 0 over gloo (FE_BENCH_SINGLE_DEVICE /
