@@ -8,6 +8,7 @@ a test can step the oracle and the HIP env side by side on the same inputs.
 from __future__ import annotations
 
 import ctypes as C
+import math
 import os
 import subprocess
 from typing import Dict, Optional, Tuple
@@ -133,7 +134,7 @@ class EpisodeStatsOracle:
         mean = s / n if n > 0 else float("nan")
         var = (ss - n * mean * mean) / (n - 1) if n > 1 else float("nan")
         out = {"num_training_episodes": int(n), "mean_training_return": mean,
-               "std_dev_training_return": max(var, 0.0) ** 0.5 if n > 1 else float("nan"),
+               "std_dev_training_return": math.sqrt(max(var, 0.0)) if n > 1 else float("nan"),  # (sqrt is correctly rounded; x ** 0.5 is not)
                "evaluation_return": float(self.eval[0]) if self.eval[1] > 0 else None}
         if reset:
             self.acc[:] = 0

@@ -126,8 +126,8 @@ for case in range(cases):
         bits(t2n(d), d_r, what + " dones")
         bits(t2n(env.cash), ref.cash, what + " cash")
         bits(t2n(env.margin), ref.margin, what + " margin")
-        bits(t2n(env.long_shares), ref.long, what + " long")
-        bits(t2n(env.short_shares), ref.short, what + " short")
+        bits(t2n(env.long_shares).astype(np.float32), ref.long, what + " long")  # (float64 on a promoted env, as the reference; same counts)
+        bits(t2n(env.short_shares).astype(np.float32), ref.short, what + " short")
         bits(t2n(env._spot0), ref.spot0, what + " spot0")
         bits(t2n(env.env_indices), ref.env_idx, what + " day indices")
         if ref_stats is not None:
