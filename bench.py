@@ -881,8 +881,8 @@ STRONG_TOTAL_ENVS = 65536  # BASELINE.json's metric: "env-steps/sec at 64k envs,
 def strong_scaling_leg(args, D: Dist, steps: int, warmup: int, world: int = None, rank: int = None):
     """The STRONG-scaling reading of the metric: 65 536 envs IN TOTAL, sharded contiguously over the world (8 GPUs: 8 192 envs
     per GPU ~ 5 us of HBM time per step -- launch-bound, where the fused / graphed forms earn their keep).  Two launch modes:
-    `eager` (env.step per step, --redraw's mode, trajectory slots written by the kernel) and `graph_k8` (rollout.GraphedRollout,
-    8 steps per hipGraph replay, redraw='device' as capture requires); with N > 1 each with and without the trajectory
+    `eager` (env.step per step, --redraw's mode, trajectory slots written by the kernel) and `graph_k8` / `graph_k32` (rollout.GraphedRollout,
+    8 / 32 steps per hipGraph replay, redraw='device' as capture requires); with N > 1 each with and without the trajectory
     all-gather (one packed chunk per `steps` eager steps resp. per 8-step replay, asynchronous, double-buffered).
     `world` / `rank`: emulate one rank's shard of a larger world on THIS GPU without collectives (the N = 1 run's preview of
     the per-GPU step time at 2 / 4 / 8 GPUs: the measured basis of DESIGN.md section 7's strong-scaling rows)."""
@@ -897,8 +897,6 @@ def strong_scaling_leg(args, D: Dist, steps: int, warmup: int, world: int = None
     _, _, A, W = CONFIGS[2]
     prices, day_id, _ = make_series(A)
     gathering = D.multi and not emulated
-    K = 8
-    steps_g = (steps + K - 1) // K * K
     out = {"total_envs": STRONG_TOTAL_ENVS, "world": w, "emulated_on_one_gpu": emulated}
 
     def fence(trajs=()):
@@ -971,43 +969,48 @@ def strong_scaling_leg(args, D: Dist, steps: int, warmup: int, world: int = None
         fence((traj,))
         out["eager"]["packed_bytes_per_rank_per_chunk"] = traj._nbytes
     del env, traj, kt
-    # ---- hipGraph, K steps per replay (two graphs over two trajectory chunks: chunk i is gathered while graph 1 - i replays)
-    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=STRONG_TOTAL_ENVS, rank=r, world_size=w,
-                                    device_id=D.local_rank, redraw="device", seed=1234, obs_buffers=2)
-    trajs = [TrajectoryBuffer(K, n, A, device=dev) for _ in range(2)]
-    rolls = [GraphedRollout(env, lambda obs, k: actions[k % 8], K, trajectory=t) for t in trajs]
-    pending = [None, None]
-    gathered = [None, None]
+    # ---- hipGraph, K steps per replay (two graphs over two trajectory chunks: chunk i is gathered while graph 1 - i replays).
+    # K = 8 is the leg VERDICT round 4 named; K = 32 shows what a longer replay buys once a collective per replay is in the loop
+    # (its host start + latency are per replay, the steps per replay amortise them)
+    for K in (8, 32):
+        steps_g = (steps + 2 * K - 1) // (2 * K) * (2 * K)  # whole replays, both graphs equally often
+        env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=STRONG_TOTAL_ENVS, rank=r, world_size=w,
+                                        device_id=D.local_rank, redraw="device", seed=1234, obs_buffers=2)
+        trajs = [TrajectoryBuffer(K, n, A, device=dev) for _ in range(2)]
+        rolls = [GraphedRollout(env, lambda obs, k: actions[k % 8], K, trajectory=t) for t in trajs]
+        pending = [None, None]
+        gathered = [None, None]
 
-    def graph_block():
-        for j in range(steps_g // K):
-            i = j & 1
-            if pending[i] is not None:
-                pending[i].wait()  # (stream-level for RCCL) chunk i has left before graph i overwrites it
-                pending[i] = None
-            rolls[i].run()
-            if gather[0]:
-                if gathered[i] is None:
-                    gathered[i] = torch.empty((D.dist.get_world_size(), trajs[i]._nbytes), dtype=torch.uint8, device=dev)
-                pending[i] = D.dist.all_gather_into_tensor(gathered[i].view(-1), trajs[i]._packed, async_op=True)
+        def graph_block():
+            for j in range(steps_g // K):
+                i = j & 1
+                if pending[i] is not None:
+                    pending[i].wait()  # (stream-level for RCCL) chunk i has left before graph i overwrites it
+                    pending[i] = None
+                rolls[i].run()
+                if gather[0]:
+                    if gathered[i] is None:
+                        gathered[i] = torch.empty((D.dist.get_world_size(), trajs[i]._nbytes), dtype=torch.uint8, device=dev)
+                    pending[i] = D.dist.all_gather_into_tensor(gathered[i].view(-1), trajs[i]._packed, async_op=True)
 
-    def graph_fence_extra():
-        for i in (0, 1):
-            if pending[i] is not None:
-                pending[i].wait()
-                pending[i] = None
+        def graph_fence_extra():
+            for i in (0, 1):
+                if pending[i] is not None:
+                    pending[i].wait()
+                    pending[i] = None
 
-    class _Drain:  # fence() drains these like a TrajectoryBuffer
-        drain = staticmethod(graph_fence_extra)
+        class _Drain:  # fence() drains these like a TrajectoryBuffer
+            drain = staticmethod(graph_fence_extra)
 
-    out["graph_k8"] = {"no_all_gather": blocks_of(graph_block, steps_g, (_Drain,))}
-    if gathering:
-        gather[0] = True
-        out["graph_k8"]["with_all_gather"] = blocks_of(graph_block, steps_g, (_Drain,))
-        gather[0] = False
-        fence((_Drain,))
-        out["graph_k8"]["packed_bytes_per_rank_per_chunk"] = trajs[0]._nbytes
-    del rolls, trajs, env, gathered
+        key = f"graph_k{K}"
+        out[key] = {"no_all_gather": blocks_of(graph_block, steps_g, (_Drain,))}
+        if gathering:
+            gather[0] = True
+            out[key]["with_all_gather"] = blocks_of(graph_block, steps_g, (_Drain,))
+            gather[0] = False
+            fence((_Drain,))
+            out[key]["packed_bytes_per_rank_per_chunk"] = trajs[0]._nbytes
+        del rolls, trajs, env, gathered
     gc.collect()
     torch.cuda.empty_cache()
     return out

@@ -73,7 +73,7 @@ def test_default_driver_command_every_leg_kernel_below_step_and_both_scaling_rea
     assert rs["steps"] == 20 and rs["blocks"] >= 5 and rs["value"] > 0
     st = d["strong_scaling"]
     assert "error" not in st and st["total_envs"] == 65536 and st["world"] == 1 and st["envs_per_gpu"] == 65536
-    for mode in ("eager", "graph_k8"):
+    for mode in ("eager", "graph_k8", "graph_k32"):
         assert st[mode]["no_all_gather"]["value"] > 0 and "with_all_gather" not in st[mode]
     assert [p["world"] for p in st["shard_preview"]] == [2, 4, 8]
     assert [p["envs_per_gpu"] for p in st["shard_preview"]] == [32768, 16384, 8192]
@@ -86,9 +86,9 @@ def test_default_driver_command_every_leg_kernel_below_step_and_both_scaling_rea
 def _check_strong_and_guard(m, ranks, envs_per_gpu):
     st = m["strong"]
     assert st["total_envs"] == 65536 and st["world"] == ranks and st["envs_per_gpu"] == envs_per_gpu and not st["emulated_on_one_gpu"]
-    for mode in ("eager", "graph_k8"):
+    for mode, slots in (("eager", 20), ("graph_k8", 8), ("graph_k32", 32)):
         assert st[mode]["no_all_gather"]["value"] > 0 and st[mode]["with_all_gather"]["value"] > 0
-        assert st[mode]["packed_bytes_per_rank_per_chunk"] == (20 if mode == "eager" else 8) * envs_per_gpu * 16
+        assert st[mode]["packed_bytes_per_rank_per_chunk"] == slots * envs_per_gpu * 16
     g = m["device_guard"]
     assert g["pass"] is True and len(g["ranks"]) == ranks
     assert all(r["env_device"] == r["local_rank"] for r in g["ranks"])

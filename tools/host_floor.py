@@ -3,7 +3,7 @@
     python tools/host_floor.py
 """
 import os, sys, time, torch, statistics
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import finenvs_amd
 from bench import make_series
 prices, day_id, _ = make_series(1)
