@@ -276,6 +276,11 @@ class Dist:
         if os.environ.get("FE_BENCH_SINGLE_DEVICE") == "1":
             self.local_rank = 0
         self.backend = os.environ.get("FE_BENCH_BACKEND", "nccl")  # "nccl" is RCCL on ROCm
+        # a launcher that narrows each rank's view to its own GPU (HIP_VISIBLE_DEVICES per rank) leaves LOCAL_RANK pointing
+        # past the one device the rank can see
+        ndev = torch.cuda.device_count()
+        if ndev and self.local_rank >= ndev:
+            self.local_rank %= ndev
         torch.cuda.set_device(self.local_rank)
         self.dev = f"cuda:{self.local_rank}"
         self.dist = None
