@@ -1,0 +1,123 @@
+"""CPU: the host logic of the public-state properties (TSE:245-269) on a TimeSeriesEnv whose bound storage is made of CPU
+tensors -- no native library, no GPU: what an assignment copies, casts, validates and refuses.  The GPU half
+(tests/test_public_state_gpu.py) shows that the kernel keeps writing the storage these properties return."""
+import pytest
+import torch
+
+from finenvs_amd.environments.time_series_env import TimeSeriesEnv
+
+
+def host_env(N=6, A=1, W=4, D=3, L=20, evaluate=True):
+    env = TimeSeriesEnv.__new__(TimeSeriesEnv)
+    env._dev = torch.device("cpu")
+    env.num_intervals, env.num_assets, env.evaluate = W, A, evaluate
+    env.world_size, env.rank = 1, 0
+    env.starting_balance = 1000.0
+    env.price_environments = torch.zeros((D, L, 4 * A), dtype=torch.float64)
+    env._num_envs = N
+    env._env_indices = torch.arange(N) % D
+    env._spot0 = torch.zeros((N,), dtype=torch.int64)
+    env._cash = torch.full((N, A), 1000.0)
+    env._long = torch.zeros((N, A))
+    env._short = torch.zeros((N, A))
+    env._margin = torch.zeros((N, A), dtype=torch.float64)
+    env._terminated = torch.zeros((N,), dtype=torch.uint8)
+    env._returns = torch.zeros((N,))
+    env._counters = torch.zeros((2,), dtype=torch.int64)
+    env.shares_promoted = False
+    env.obs_buffers = 0
+    env._handle = env._lib = None  # (__del__ / _release_native: nothing to destroy)
+    return env
+
+
+def test_assignment_copies_into_the_bound_storage_with_the_references_dtypes():
+    env = host_env()
+    bound = {k: getattr(env, k) for k in ("cash", "margin", "long_shares", "short_shares", "env_indices", "episode_returns")}
+    ptrs = {k: v.data_ptr() for k, v in bound.items()}
+    t = 250.0 * torch.ones((6, 1), dtype=torch.float64)
+    env.cash = t                                    # f64 in, f32 held (the reference's cash is f32)
+    env.margin = torch.ones((6, 1))                 # f32 in, f64 held (TSE:376-383)
+    env.long_shares = torch.full((6,), 2)           # int64 (6,) in, f32 (6, 1) held
+    env.short_shares = [[1.0]] * 6                  # anything torch.as_tensor takes
+    env.env_indices = torch.tensor([2, 1, 0, 2, 1, 0], dtype=torch.int32)
+    env.episode_returns = torch.arange(6)
+    assert {k: getattr(env, k).data_ptr() for k in bound} == ptrs          # nothing was re-bound
+    assert env.cash is bound["cash"] and env.cash is not t and env.cash.dtype is torch.float32 and float(env.cash.sum()) == 1500.0
+    assert env.margin.dtype is torch.float64 and float(env.margin.sum()) == 6.0
+    assert env.long_shares.dtype is torch.float32 and tuple(env.long_shares.shape) == (6, 1) and float(env.long_shares[3]) == 2.0
+    assert float(env.short_shares.sum()) == 6.0
+    assert env.env_indices.dtype is torch.int64 and env.env_indices.tolist() == [2, 1, 0, 2, 1, 0]
+    assert env.episode_returns.tolist() == [0.0, 1.0, 2.0, 3.0, 4.0, 5.0]
+    t.zero_()                                       # the assigned tensor is not aliased ...
+    assert float(env.cash.sum()) == 1500.0
+    env.cash[:2] = 7.0                              # ... the returned one IS the bound storage
+    assert float(env._cash[:2].sum()) == 14.0
+
+
+def test_terminated_episodes_is_a_bool_view_and_keeps_the_count():
+    env = host_env()
+    assert env.terminated_episodes.dtype is torch.bool and env.terminated_episodes.data_ptr() == env._terminated.data_ptr()
+    env.terminated_episodes = torch.tensor([1, 0, 1, 1, 0, 0])
+    assert env._terminated.tolist() == [1, 0, 1, 1, 0, 0] and int(env._counters[0]) == 3
+    env.terminated_episodes[1] = True               # in-place edits reach the kernel's flags
+    assert env._terminated.tolist() == [1, 1, 1, 1, 0, 0]
+
+
+def test_env_spots_and_pointers_are_derived():
+    env = host_env()
+    assert env.env_spots.tolist() == [[0, 1, 2, 3]] * 6 and env.env_pointers.tolist() == [0] * 6
+    env.env_spots = (torch.arange(0, 4) + torch.arange(6).unsqueeze(1))
+    assert env._spot0.tolist() == [0, 1, 2, 3, 4, 5] and env.env_pointers.tolist() == [0, 1, 2, 3, 4, 5]
+    env.env_pointers = torch.arange(6)              # equal to env_spots[:, 0]: accepted (the reference's recipe assigns it)
+    with pytest.raises(ValueError, match="derived"):
+        env.env_pointers = torch.zeros(6, dtype=torch.int64)
+    with pytest.raises(ValueError, match="consecutive"):
+        env.env_spots = torch.zeros((6, 4), dtype=torch.int64)
+    with pytest.raises(ValueError, match=r"must be \(6, 4\)"):
+        env.env_spots = torch.zeros((6, 5), dtype=torch.int64)
+    with pytest.raises(ValueError, match="out of range"):
+        env.env_spots = (torch.arange(0, 4) + 16).repeat(6, 1)   # spot0 + W must stay below L = 20
+    env.env_spots = (torch.arange(0, 4) + 15).repeat(6, 1)
+    assert env._spot0.tolist() == [15] * 6
+
+
+def test_setters_refuse_what_does_not_fit():
+    env = host_env()
+    with pytest.raises(ValueError, match="expected 6 values"):
+        env.cash = torch.ones((7, 1))
+    with pytest.raises(ValueError, match="expected 6 values"):
+        env.margin = torch.ones((3,))
+    with pytest.raises(ValueError, match="follows env_indices"):
+        env.num_envs = 7
+    env.num_envs = 6
+    with pytest.raises(ValueError, match="day indices"):
+        env.env_indices = torch.tensor([0, 1, 2, 3, 0, 1])       # D = 3
+    with pytest.raises(ValueError, match="day indices"):
+        env.env_indices = torch.tensor([-1, 1, 2, 0, 0, 1])
+    sharded = host_env()
+    sharded.world_size = 2
+    with pytest.raises(ValueError, match="sharded"):
+        sharded.env_indices = torch.arange(8) % 3
+
+
+def test_another_length_rebuilds_the_env(monkeypatch):
+    """Assigning env_indices of another length (SURVEY Appendix B's first statement) releases the native env and allocates
+    the state for the new N; the evaluation env of a training-mode env is the LAST env of the new batch (TSE:253-257, 510)."""
+    env = host_env(evaluate=False)
+    calls = []
+    monkeypatch.setattr(TimeSeriesEnv, "_release_native", lambda self: calls.append("release"))
+    monkeypatch.setattr(TimeSeriesEnv, "_allocate_state",
+                        lambda self, idx, total, lo, obs_buffers: calls.append(("allocate", idx.tolist(), total, lo, obs_buffers)))
+    env.env_indices = torch.arange(8) % 3
+    assert calls == ["release", ("allocate", [0, 1, 2, 0, 1, 2, 0, 1], 8, 0, 0)] and env._eval_env == 7
+
+
+def test_promoted_env_shows_float64_share_tensors():
+    env = host_env()
+    env._long[:] = 3.0
+    assert env.long_shares.dtype is torch.float32 and env.long_shares is env._long
+    env.shares_promoted = True                       # what step() records after a launched float64-action step
+    assert env.long_shares.dtype is torch.float64 and env.short_shares.dtype is torch.float64   # TSE:361, 375
+    assert float(env.long_shares.sum()) == 18.0 and env._long.dtype is torch.float32
+    env.long_shares = torch.ones((6, 1), dtype=torch.float64)   # written through assignment
+    assert float(env._long.sum()) == 6.0
