@@ -153,8 +153,8 @@ def is_step_kernel(name: str) -> bool:
 def step_kernel_name(W: int, A: int, f32: bool, form: int) -> str:
     """The demangled instantiation fe_env_kernel<OT, VEC, SINGLE, RESET_ONLY, FORM> a step launch dispatches to (as
     rocprofv3's kernel trace names it, minus the anonymous namespace): OT / VEC as fe_env_create picks them (16-byte
-    packs unless W*5*A is odd), FORM 0 lean (plain fe_env_step), 1 full (trajectory outputs / statistics / evaluate
-    mode), 2 / 3 the same with the host flag (redraw='torch')."""
+    packs unless W*5*A is odd), FORM 0 lean (plain step, or with the action copy), 1 full (trajectory DESCRIPTORS / statistics /
+    evaluate mode), 2 / 3 the same with the host flag (redraw='torch')."""
     vec = 4 if f32 else 2
     while vec > 1 and (W * 5 * A) % vec:
         vec //= 2
@@ -379,8 +379,9 @@ class Dist:
 
 class KernelTrain:
     """Back-to-back launches of the step kernel straight through the C ABI -- the SAME entry point and FORM the timed loop's
-    env.step() dispatches to: fe_env_step_traj (FORM 1: trajectory outputs) or, when this env polls a host flag
-    (redraw='torch' on the rank that owns the evaluation env), fe_env_step_traj_notify (FORM 3) -- with preallocated outputs and
+    env.step() dispatches to: fe_env_step_traj with the action copy (FORM 0: rewards / dones / action copy into trajectory slots
+    need no more than the lean form) or, when this env polls a host flag (redraw='torch' on the rank that owns the evaluation
+    env), fe_env_step_traj_notify (FORM 2) -- with preallocated outputs and
     no per-step Python work, so the queue never drains; ONE pair of HIP events on the launch stream brackets the train
     (torch's current stream is the stream the C ABI launches on).  interval = kernel + launch boundary.  Uses the env's own
     observation ring (the HBM / MALL regime of the timed region).  The host flag is written, never read, inside a train: the
@@ -394,7 +395,7 @@ class KernelTrain:
         self.act = torch.empty((N, env.num_assets), dtype=torch.float32, device=dev)  # agent.store's action copy
         self.aptr = [a.data_ptr() for a in actions]
         self.notify = env._flag is not None and not env.evaluate
-        self.form = 3 if self.notify else 1
+        self.form = 2 if self.notify else 0
 
     def run(self, k: int) -> float:
         """ms per launch of one train of k launches."""
@@ -708,8 +709,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBPS, "traffic": traffic, "traffic_source": traffic_source,
             # the instantiation the trains AND the timed loop launch (the row to look up in profiles/*_kernel_stats.csv):
-            # env.step with trajectory slots = fe_env_step_traj (FORM 1), or -- redraw='torch' on the rank that owns the
-            # evaluation env -- its host-flag variant fe_env_step_traj_notify (FORM 3: same arithmetic, the evaluation env's
+            # env.step with rewards / dones / action copy into trajectory slots = fe_env_step_traj on the lean form (FORM 0), or --
+            # redraw='torch' on the rank that owns the evaluation env -- fe_env_step_traj_notify (FORM 2: same arithmetic, the evaluation env's
             # tile first)
             "kernel": step_kernel_name(W, A, args.obs_f32, form),
             "timed_loop_kernel": step_kernel_name(W, A, args.obs_f32, 0 if roll is not None else form),  # (--graph: plain env.step, the lean form)

@@ -175,8 +175,9 @@ static hipError_t prepare_kernel(int device, const void *kern, int block, size_t
 }
 
 // The kernel instantiation a given env dispatches to (shared by launch and occupancy query).  FORM (fe_step_kernel.h):
-// kFull = the launch has optional outputs (evaluate-mode bookkeeping, episode statistics, trajectory descriptors /
-// action copy), kLean = none of them, kNotify = lean + the host flag of fe_env_step_notify; same launch bounds, same LDS.
+// kFull = the launch has optional outputs (evaluate-mode bookkeeping, episode statistics, trajectory descriptors), kLean =
+// none of them (the action copy of fe_env_step_traj is written by every form), kNotify = lean + the host flag of
+// fe_env_step_notify; same launch bounds, same LDS.
 template <bool RESET_ONLY, int FORM>
 static const void *kernel_for(bool f32, int vec, bool single) {
 #define FE_PICK(OT, VEC) \
@@ -222,7 +223,8 @@ static int launch_env(const fe_env *env, const float *actions, void *obs, double
     DeviceGuard guard(env->device);
     if (guard.err != hipSuccess) return hip_fail(guard.err, "hipSetDevice");
     const bool f32 = env->cfg.obs_is_f32 != 0, single = p.A == 1;
-    const bool full = !RESET_ONLY && (p.evaluate || p.run_ret || desc_src || act_store);
+    // (the action copy alone does not need the full form: every form writes it)
+    const bool full = !RESET_ONLY && (p.evaluate || p.run_ret || desc_src);
     const void *kern = RESET_ONLY ? kernel_for<true, kLean>(f32, env->vec, single)
                        : (host_flag ? (full ? kernel_for<false, kFullNotify>(f32, env->vec, single) : kernel_for<false, kNotify>(f32, env->vec, single))
                                     : (full ? kernel_for<false, kFull>(f32, env->vec, single) : kernel_for<false, kLean>(f32, env->vec, single)));

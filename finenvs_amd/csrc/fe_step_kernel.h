@@ -8,8 +8,8 @@ namespace {
 // (it holds barriers).  On return l.src / l.pos describe the observation of this step (terminal
 // window on done steps, exactly what step() returns, TSE:321) and the state arrays hold the
 // post-step (post-reset) state.
-// FORM: kLean = launches that have none of the optional outputs (evaluate-mode bookkeeping, episode statistics,
-// trajectory descriptors / action copy): their eight pointers never become live scalars; kFull = all of them;
+// FORM: kLean = launches that have none of the optional outputs but the action copy (no evaluate-mode bookkeeping, episode
+// statistics or trajectory descriptors): their pointers never become live scalars; kFull = all of them;
 // kNotify / kFullNotify = the lean / full form + the host flag of fe_env_step_notify / fe_env_step_traj_notify (and their
 // last-tile-first walk).
 constexpr int kLean = 0, kFull = 1, kNotify = 2, kFullNotify = 3;
@@ -91,8 +91,12 @@ __device__ __forceinline__ void account_core(const Params &p, const TileLds &l, 
                 p.desc_pos[sl] = s.pos_obs;
                 if (a == 0) p.desc_src[n] = l.src[e];
             }
-            if (p.act_store) p.act_store[sl] = (float)action;  // agent.store's `actions` field, no copy kernel (f32 actions only)
         }
+        // agent.store's `actions` field, no copy kernel (f32 actions only) -- in EVERY form: one resident pointer, and a rollout
+        // loop that has the kernel write rewards / dones / its action copy into trajectory slots (what bench.py times) stays on the
+        // lean forms: 28.26 instead of 28.57 us (plain) and 28.55 instead of 29.00 us (host flag) at config 2 against the round-4
+        // dispatch that sent the action copy to the full forms (profiles/r05_microbench/form_ab.txt, 'leanact')
+        if (p.act_store) p.act_store[sl] = (float)action;
     }
     // ---------------- phase 1b: one lane per env ----------------
     bool any = sdone;

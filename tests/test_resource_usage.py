@@ -63,9 +63,10 @@ def test_step_kernels_keep_their_occupancy(table):
 
 def test_lean_step_kernel_has_fewer_scalar_spills_than_the_full_one(table):
     """fe_env_kernel<..., FORM = 0> exists so that the optional outputs' pointers never become live scalars
-    (profiles/r03_microbench/lean_vs_full.txt): 48 SGPR spills in round 2's only form, ~10 in the lean one."""
+    (profiles/r03_microbench/lean_vs_full.txt): 48 SGPR spills in round 2's only form, ~10 in the lean one (17 since round 5,
+    when the lean forms took over the action copy: one more resident pointer, same launch time)."""
     got = {r["name"]: r["sgpr_spill"] for r in table}
-    assert got["fe_env_kernel<double, 2, true, false, 0>"] <= 16
+    assert got["fe_env_kernel<double, 2, true, false, 0>"] <= 20
     assert got["fe_env_kernel<double, 2, true, false, 0>"] < got["fe_env_kernel<double, 2, true, false, 1>"]
     assert got["fe_env_kernel<double, 2, true, false, 2>"] < got["fe_env_kernel<double, 2, true, false, 1>"]
 

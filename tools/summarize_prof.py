@@ -165,7 +165,9 @@ def main():
                 f"--warmup {bench['warmup']} --no-cpu --no-extra --no-pmc --no-audition --repeats 2{' --obs-f32' if bench['dtype'] == 'f32' else ''}` "
                 f"(+ separate `--pmc FETCH_SIZE` and `--pmc WRITE_SIZE` passes); `--no-audition`: every launch of the run writes the ring as allocated\n\n")
         form = headline_kernel.rstrip(">").split(",")[-1].strip()
-        entry = {"1": "FORM 1 = the full form, `fe_env_step_traj`", "3": "FORM 3 = the full form with the host flag of redraw='torch', `fe_env_step_traj_notify`"}.get(form, f"FORM {form}")
+        entry = {"0": "FORM 0 = the lean form (it writes the action copy too), `fe_env_step_traj` with `actions_out` only",
+                 "1": "FORM 1 = the full form, `fe_env_step_traj`", "2": "FORM 2 = the lean form with the host flag of redraw='torch', `fe_env_step_traj_notify` with `actions_out` only",
+                 "3": "FORM 3 = the full form with the host flag of redraw='torch', `fe_env_step_traj_notify`"}.get(form, f"FORM {form}")
         f.write(f"**The kernel the bench line times: `{headline_kernel}`** (`roofline.kernel`; {entry}: launched by the timed "
                 f"loop's `env.step(..., rewards_out, dones_out, actions_out)` and by the C-ABI trains that alternate with its blocks; "
                 f"eval_redraw = {bench['config'].get('eval_redraw')}).\n\n")
