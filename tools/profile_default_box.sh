@@ -16,7 +16,7 @@ for e in b["extra_configs"]:
 lines += ["", "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
 for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"]))[:8]:
     lines.append(f"| `{r['Name'].replace('(anonymous namespace)::', '')[:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")
-lines += ["", "(`fe_env_kernel<double, 2, true, false, 3>` is the config-2 step kernel as the headline's loop and trains launch it (redraw='torch' with trajectory outputs: the full + host-flag form); `..., 1>` = the full form without the flag (the `device_redraw` leg and the hipGraph strong-scaling legs: trajectory outputs, redraw='device'), `..., 0>` = the lean form (`two_streams`), `..., 2>` = lean + host flag (`reference_semantics`: class defaults).  The single-asset instantiations also serve the strong-scaling legs at 8 192 - 65 536 envs, and `<double, 2, false, false, *>` serves configs 3, 4 and 5 in the same process, so their averages mix launches of very different sizes: per-config figures are in `profiles/<tag>_c<cfg>_summary.md`.)"]
+lines += ["", "(`fe_env_kernel<double, 2, true, false, 2>` is the config-2 step kernel as the headline's loop and trains launch it (redraw='torch' with rewards / dones / action copy in trajectory slots: the lean + host-flag form; also the `reference_semantics` leg); `..., 0>` = the lean form without the flag (the `device_redraw` leg, the hipGraph strong-scaling legs, `two_streams`); `..., 1>` / `..., 3>` = the full forms (descriptors / statistics / evaluate mode: not launched by this command).  The single-asset instantiations also serve the strong-scaling legs at 8 192 - 65 536 envs, and `<double, 2, false, false, *>` serves configs 3, 4 and 5 in the same process, so their averages mix launches of very different sizes: per-config figures are in `profiles/<tag>_c<cfg>_summary.md`.)"]
 with open(os.path.join(out, f"{tag}_default_cmd_summary.md"), "w") as f:  # gpurun merges gpurun_out/ back: copy it to profiles/ from there
     f.write("\n".join(lines) + "\n")
 print("\n".join(lines))
