@@ -94,6 +94,42 @@ def test_appendix_b_recipe_then_the_references_own_rollout(fe, prebuilt):
     assert g["dones"].sum() > 100
 
 
+def test_appendix_b_recipe_in_training_mode_then_the_references_own_rollout(fe):
+    """rollout_train_n64.npz: the reference in TRAINING mode (native N = D + 1 with the evaluation env on a drawn day), scaled
+    to 64 envs by the recipe, stepped 150 times across day ends with the evaluation env -- the LAST env of the scaled batch
+    (TSE:510 reads dones[-1]) -- redrawing its day.  The same on a HIP env with the class defaults (redraw='torch': the host flag
+    follows the resize); the fixture's redrawn days come from torch's CPU generator and are imposed where the GPU generator
+    drew another day, everything else is the reference's, bit for bit."""
+    from finenvs_amd import _lib
+
+    g = load_golden("rollout_train_n64.npz")
+    W, N = int(g["W"]), int(g["N"])
+    torch.manual_seed(int(g["torch_seed"]))
+    env = fe.TimeSeriesEnv(tables=(g["prices"], g["logret"]), num_intervals=W, **econ_kwargs(g))
+    D = env.price_environments.shape[0]
+    assert env.num_envs == D + 1 and env.redraw == "torch" and env._flag is not None and env._eval_env == D
+    appendix_b_recipe(env, N)
+    assert env.num_envs == N and env._eval_env == N - 1 and env._flag is not None and env._flag.value != 0
+    assert torch.equal(env.env_indices.cpu(), torch.from_numpy(g["init_env_idx"]))
+    assert_bits(t2n(env.reset()), g["obs_reset"], "reset obs")
+    redraws = 0
+    for t in range(g["actions"].shape[0]):
+        obs, rew, done, _ = env.step(torch.from_numpy(g["actions"][t].reshape(N, 1)).to(env.device))
+        want = int(g["env_idx"][t][-1])
+        if bool(g["dones"][t][-1]):
+            redraws += 1
+        if int(env.env_indices[-1]) != want:  # (a CPU-generator draw in the fixture)
+            _lib.check(env._lib.fe_env_set_day(env._handle, N - 1, want, env._stream()))
+        what = f"training recipe step {t}"
+        assert_bits(t2n(obs), g["obs"][t], what + " obs")
+        assert_bits(t2n(rew), g["rewards"][t], what + " rewards")
+        assert_bits(t2n(done), g["dones"][t], what + " dones")
+        assert_bits(t2n(env.cash).reshape(-1), g["cash"][t], what + " cash")
+        assert_bits(t2n(env.margin).reshape(-1), g["margin"][t], what + " margin")
+        assert_bits(t2n(env.env_indices), g["env_idx"][t], what + " env_idx")
+    assert redraws >= 2
+
+
 @pytest.mark.parametrize("A,training", [(1, False), (1, True), (3, False)])
 def test_appendix_b_recipe_then_100_steps_against_the_oracle(fe, fo, A, training):
     """The recipe at a size the fixtures do not hold (N = 1000 from a 5-day env; multi-asset: (N, A) state, so the recipe's
