@@ -733,8 +733,13 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         },
     }
     if D.multi:
+        forms = [None] * D.dist.get_world_size()
+        D.dist.all_gather_object(forms, int(form))
         res["multi_gpu"] = {
             "ranks_seen": D.dist.get_world_size(), "collective_backend": D.backend,
+            # the step kernel's FORM per rank: only the rank that owns the evaluation env polls the host flag (FORM 2 with
+            # redraw='torch'); `roofline.kernel` above is rank 0's, `value` is the max over ranks
+            "kernel_form_by_rank": forms,
             "trajectory_slots": T, "all_gather_every_steps": T,
             "all_gather_issue": "asynchronous; chunks switch at the first step after a chunk is full, the collective is started two steps later "
                                 "(its host cost then hides behind queued steps); drained inside the timed block",

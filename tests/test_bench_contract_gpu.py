@@ -124,6 +124,7 @@ def test_bench_n_gt_1_code_path_over_rccl_with_one_rank():
     assert d["multi_gpu"]["collective_backend"] == "nccl"
     _check_multi_gpu_object(d["multi_gpu"], 1)
     _check_strong_and_guard(d["multi_gpu"], 1, 65536)
+    assert d["multi_gpu"]["kernel_form_by_rank"] == [2]
     assert "rccl" in d["multi_gpu"] and d["multi_gpu"]["rccl"] is not None
     # value is the with-all-gather leg
     assert abs(d["value"] - d["multi_gpu"]["value_with_all_gather"]) / d["value"] < 1e-9
@@ -166,6 +167,7 @@ def test_bench_two_ranks_through_torch_distributed_run():
     assert d["n_gpus"] == 2 and d["scaling"] == "weak"
     _check_multi_gpu_object(d["multi_gpu"], 2)
     _check_strong_and_guard(d["multi_gpu"], 2, 32768)  # the strong-scaling leg: 64k envs in total over the two ranks
+    assert d["multi_gpu"]["kernel_form_by_rank"] == [0, 2]  # only the last rank owns the evaluation env and polls the host flag
     assert d["multi_gpu"]["collective_backend"] == "gloo"
     # weak scaling: every rank owns the config's full env count; value counts all ranks' envs
     assert d["config"]["envs_per_gpu"] == 65536
