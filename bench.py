@@ -412,14 +412,14 @@ class KernelTrain:
             e0.record()
             for i in range(k):
                 seq = (seq + 1) & 0x3FFFFFFFFFFFFFFF
-                rc |= fn(h, aptr[i % 8], obs[i % nb], rp, dp, ap, None, None, flag, seq, stream)
+                rc = fn(h, aptr[i % 8], obs[i % nb], rp, dp, ap, None, None, flag, seq, stream) or rc  # (keeps a failure's code)
             e1.record()
             env._flag_seq = seq
         else:
             fn = env._lib.fe_env_step_traj
             e0.record()
             for i in range(k):
-                rc |= fn(h, aptr[i % 8], obs[i % nb], rp, dp, ap, None, None, stream)
+                rc = fn(h, aptr[i % 8], obs[i % nb], rp, dp, ap, None, None, stream) or rc
             e1.record()
         torch.cuda.synchronize()
         env._generation += k
