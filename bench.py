@@ -138,7 +138,8 @@ def pmc_traffic(config: int, f32: bool):
     return ent.get("bytes_per_launch"), f"profiles/hbm_traffic.json[{key}], run tag {ent.get('tag')} (separate --pmc FETCH_SIZE / WRITE_SIZE passes, 2*FETCH+WRITE)"
 
 
-_LIVE_PMC_BROKEN = []  # first failure of a live counter pass: later workloads fall back to the committed figures
+_LIVE_PMC_BROKEN = []  # "no profiler can run in this process at all" (already profiled / no rocprofv3): never asked again
+PMC_CHILD_TIMEOUT_S = 150.0  # one counter-pass child (import + tables + a 154 GB first touch + 16 launches under the profiler)
 _PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_", "ROCTX_")
 
 
@@ -186,11 +187,25 @@ def pmc_child_env(environ=None) -> dict:
     return env
 
 
+def _last_words(path: str, limit: int = 110) -> str:
+    """The last informative line of a child's stderr (what made it exit), shortened for the bench line."""
+    try:
+        with open(path, errors="replace") as f:
+            lines = [ln.strip() for ln in f if ln.strip()]
+    except OSError:
+        return ""
+    for ln in reversed(lines):
+        if any(w in ln for w in ("Error", "error", "Exception", "failed", "Killed", "fault", "abort", "terminate")):
+            return ln[:limit]  # (a Python traceback's last line starts with the exception's name and reason)
+    return lines[-1][:limit] if lines else ""
+
+
 def live_pmc_traffic(config: int, f32: bool, redraw: str, no_audition: bool = False):
     """HBM traffic per launch MEASURED IN THIS RUN: two child processes of this very script (`--pmc-child`: the same
     workload, 16 launches) under `rocprofv3 --pmc FETCH_SIZE` and `--pmc WRITE_SIZE` -- separate passes, as
     MI355X_MICROARCH.md's HBM section prescribes; both counters are KiB; FETCH_SIZE is doubled (gfx950 tallies 128-B
-    requests at 64 B).  Returns (bytes per launch, description) or (None, reason)."""
+    requests at 64 B).  Returns (bytes per launch, description) or (None, cause).  A failure of one config's children is
+    that config's alone (its cause = the child's own last stderr line); only "no profiler can run here at all" is remembered."""
     import csv
     import glob
     import shutil
@@ -210,46 +225,66 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str, no_audition: bool = Fa
     vals = {}
     try:
         for kind in ("FETCH_SIZE", "WRITE_SIZE"):
+            # the interpreter itself directly after `--` (no env / shell hop: the profiler's preloaded library has the GPU
+            # initialised before the program starts)
             cmd = [exe, "--pmc", kind, "--output-format", "csv", "-d", os.path.join(out, kind), "--",
                    sys.executable, os.path.abspath(__file__), "--pmc-child", "--config", str(config), "--redraw", redraw]
             if f32:
                 cmd.append("--obs-f32")
             if no_audition:
                 cmd.append("--no-audition")
-            r = subprocess.run(cmd, cwd="/tmp", env=pmc_child_env(), stdout=subprocess.DEVNULL,
-                               stderr=subprocess.DEVNULL, timeout=90)
+            errp = os.path.join(out, kind + ".err")
+            try:
+                with open(errp, "w") as ef:
+                    r = subprocess.run(cmd, cwd="/tmp", env=pmc_child_env(), stdout=subprocess.DEVNULL, stderr=ef, timeout=PMC_CHILD_TIMEOUT_S)
+            except subprocess.TimeoutExpired:
+                return None, f"--pmc {kind} child of config {config} not done after {PMC_CHILD_TIMEOUT_S:g} s: {_last_words(errp, 60)}"
             if r.returncode != 0:
-                _LIVE_PMC_BROKEN.append(f"rocprofv3 --pmc {kind} child exited with {r.returncode}")
-                return None, _LIVE_PMC_BROKEN[0]
+                return None, f"--pmc {kind} child of config {config} exited {r.returncode}: {_last_words(errp)}"
             rows = []
             for f in glob.glob(os.path.join(out, kind, "*", "*_counter_collection.csv")):
                 for row in csv.DictReader(open(f)):
                     if is_step_kernel(row["Kernel_Name"]) and row["Counter_Name"] == kind:
                         rows.append(float(row["Counter_Value"]))
             if len(rows) < 8:
-                return None, f"no {kind} rows for the step kernel"
+                return None, f"{len(rows)} {kind} rows for the step kernel of config {config} (16 expected)"
             rows = rows[len(rows) // 4:]  # drop the warm-up launches
             vals[kind] = (sum(rows) / len(rows), len(rows))
-    except Exception as exc:  # noqa: BLE001  (incl. the 90 s timeout: never try again in this run)
-        _LIVE_PMC_BROKEN.append(f"{type(exc).__name__}: {exc}")
-        return None, _LIVE_PMC_BROKEN[0]
+    except Exception as exc:  # noqa: BLE001
+        return None, f"{type(exc).__name__}: {exc}"[:140]
     finally:
         shutil.rmtree(out, ignore_errors=True)
     traffic = (2.0 * vals["FETCH_SIZE"][0] + vals["WRITE_SIZE"][0]) * 1024.0
-    return traffic, (f"measured in this run: rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE child passes of bench.py "
-                     f"({vals['FETCH_SIZE'][1]} / {vals['WRITE_SIZE'][1]} launches averaged; 2*FETCH_SIZE + WRITE_SIZE, KiB -> bytes)")
+    return traffic, (f"measured in this run: --pmc FETCH_SIZE / WRITE_SIZE children, {vals['FETCH_SIZE'][1]}/{vals['WRITE_SIZE'][1]} launches")
+
+
+def wait_for_free_memory(dev, need: int, limit_s: float = 60.0) -> int:
+    """A previous owner's buffers (this process's last workload, or another process that has just exited) are given back
+    asynchronously: a 150 GB allocation can take seconds to reappear as free memory.  Returns the free bytes seen last."""
+    t0 = time.perf_counter()
+    free = torch.cuda.mem_get_info(dev)[0]
+    while free < need and time.perf_counter() - t0 < limit_s:
+        gc.collect()
+        torch.cuda.empty_cache()
+        time.sleep(0.5)
+        free = torch.cuda.mem_get_info(dev)[0]
+    return free
 
 
 def pmc_child(args):
-    """`--pmc-child`: the headline workload's step kernel, a few launches, nothing else (what the rocprofv3 counter
-    passes of live_pmc_traffic profile)."""
+    """`--pmc-child`: the workload's step kernel in the timed loop's form, 16 launches, nothing else (what the rocprofv3 counter
+    passes of live_pmc_traffic profile).  It starts while the parent's last workload may still be on its way back to the free
+    pool (round 5: the config-4 child died allocating its 154 GB observation), so it waits for the memory like run_workload."""
     import finenvs_amd
 
     name, N, A, W = CONFIGS[args.config]
     prices, day_id, _ = make_series(A)
     obs_bytes = N * W * 5 * A * (4 if args.obs_f32 else 8)
+    obs_buffers = 2 if 2 * obs_bytes < 200e9 else 1
+    free = wait_for_free_memory("cuda:0", obs_buffers * obs_bytes + (6 << 30), 45.0)
+    print(f"[pmc-child] config {args.config}: {free / 2**30:.1f} GiB free, observation ring {obs_buffers} x {obs_bytes / 2**30:.1f} GiB", file=sys.stderr, flush=True)
     env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw=args.redraw, seed=1234,
-                                    obs_buffers=2 if 2 * obs_bytes < 200e9 else 1, obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
+                                    obs_buffers=obs_buffers, obs_dtype=torch.float32 if args.obs_f32 else torch.float64)
     if not args.no_audition:
         env.audition_ring(AUDITION_EXTRA, AUDITION_BUDGET)
     g = torch.Generator(device="cuda:0").manual_seed(7)
@@ -261,6 +296,7 @@ def pmc_child(args):
     for i in range(16):  # the timed loop's form of the step: trajectory outputs (+ the host flag with --redraw torch)
         env.step(actions[i % 8], rewards_out=rew, dones_out=done, actions_out=act)
     torch.cuda.synchronize()
+    print("[pmc-child] done", file=sys.stderr, flush=True)
 
 
 class Dist:
@@ -462,12 +498,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         obs_buffers = 2 if 2 * obs_bytes < 200e9 else 1
         # the previous workload's buffers (and those of its rocprofv3 child processes) are given back asynchronously:
         # a 150 GB allocation can take seconds to reappear as free memory after its owner has gone
-        need = obs_buffers * obs_bytes + (6 << 30)
-        t_wait = time.perf_counter()
-        while torch.cuda.mem_get_info(D.dev)[0] < need and time.perf_counter() - t_wait < 60.0:
-            gc.collect()
-            torch.cuda.empty_cache()
-            time.sleep(0.5)
+        wait_for_free_memory(D.dev, obs_buffers * obs_bytes + (6 << 30))
         env = finenvs_amd.TimeSeriesEnv(
             prices=prices, day_id=day_id, num_intervals=W, num_envs=n_per_gpu * world, rank=rank, world_size=world,
             device_id=D.local_rank, redraw=redraw, seed=1234, obs_buffers=obs_buffers,
@@ -527,10 +558,15 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         from finenvs_amd.rollout import GraphedRollout
 
         roll = GraphedRollout(env, lambda obs, k: actions[k % 8], 8)
-        run_steps = lambda n: [roll.run() for _ in range(n // 8)]  # noqa: E731
+        issue = lambda n: [roll.run() for _ in range(n // 8)]  # noqa: E731
     else:
         env.reset()
-        run_steps = lambda n: [one_step(i) for i in range(n)]  # noqa: E731
+        issue = lambda n: [one_step(i) for i in range(n)]  # noqa: E731
+    launched = [0]  # step-kernel launches so far (loop + trains): `untimed_steps_before_value` is read off it
+
+    def run_steps(n):
+        launched[0] += n
+        issue(n)
 
     def fence():
         """drain + barrier + synchronize.  N > 1 over RCCL: the barrier is enqueued behind this rank's steps and gathers, so
@@ -569,6 +605,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
                       f"({steps} steps)", file=sys.stderr, flush=True)
             if train[0] is not None:
                 trains.append(train[0].run(train[1]))
+                launched[0] += train[1]
         return out, trains
 
     run_steps(warmup)
@@ -604,6 +641,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     # headline runs on the auditioned ring.  Where the audition keeps the ring as it was (no candidate fits: configs 4 and 5;
     # none is > 3 % faster: usually config 2) both figures are the same timed blocks.
     as_allocated = None
+    before_value = None  # launches before the first block that counts towards `value`
     reuse_blocks = None  # the as-allocated blocks ARE the headline's when the audition kept the ring (on every rank)
     if not args.no_audition and roll is None:
         if D.multi:
@@ -611,6 +649,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             fence()
             traj.clear()
             run_steps(T)  # one full chunk: the first timed block has something to gather
+        before_value = launched[0]
         aa_blocks, aa_trains = timed_blocks(R)
         aa_kern = statistics.median(aa_trains)
         ring_before = [t.data_ptr() for t in env._obs_ring]
@@ -622,9 +661,7 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
                         "blocks": len(aa_blocks), "kernel_ms": aa_kern,
                         "frac_of_8TBps_wall": hbm_bytes(W, A, obs_elem) * N / (aa_block / steps) / 1e9 / HBM_PEAK_GBPS,
                         "frac_of_8TBps_kernel": hbm_bytes(W, A, obs_elem) * N / (aa_kern * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                        "ring_changed_by_audition": changed,
-                        "what": "the same timed loop and fences as `value`, on the observation ring as the allocator handed it out "
-                                "(before the placement audition)"}
+                        "ring_changed_by_audition": changed}
         if D.all_ok(not changed):
             reuse_blocks = (aa_blocks, aa_trains)
             as_allocated["same_run_as_value"] = True
@@ -645,6 +682,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         fence()
         traj.clear()
         run_steps(T)  # one full chunk: the first timed block has something to gather
+        if reuse_blocks is None:
+            before_value = launched[0]
         legs["with_all_gather"], kern = reuse_blocks if reuse_blocks is not None else timed_blocks(R)
         fence()
         gather[0] = False
@@ -671,6 +710,8 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         fence()
         traj.clear()
     else:
+        if reuse_blocks is None:
+            before_value = launched[0]
         legs["single_gpu"], kern = reuse_blocks if reuse_blocks is not None else timed_blocks(R)
         head = legs["single_gpu"]
     block = statistics.median(head)
@@ -700,7 +741,9 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
         "as_allocated": as_allocated,
         "launch": env.launch_info(),
         "launch_mode": "hipGraph x8 steps" if args.graph else "eager, one launch per step",
-        "settle_steps": settle_steps,
+        # untimed steps: `settle_steps` run straight before every timed phase (SETTLE_MS of GPU time: the post-idle clock transient,
+        # DESIGN.md section 8); `untimed_steps_before_value` = every step-kernel launch (loop + trains) before the first block of `value`
+        "settle_steps": settle_steps, "untimed_steps_before_value": before_value,
         "repeats": {name_: {"blocks": len(v), "ms_per_step_median": statistics.median(v) / steps * 1e3,
                             "ms_per_step_min": min(v) / steps * 1e3, "ms_per_step_max": max(v) / steps * 1e3,
                             "value_median": total_envs * steps / statistics.median(v)}
@@ -715,9 +758,6 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             "kernel": step_kernel_name(W, A, args.obs_f32, form),
             "timed_loop_kernel": step_kernel_name(W, A, args.obs_f32, 0 if roll is not None else form),  # (--graph: plain env.step, the lean form)
             "kernel_ms": kern_ms,
-            "kernel_ms_regime": "median of the trains that ALTERNATE with the timed blocks (block, train, block, train ...): "
-                                "back-to-back C-ABI launches of the loop's own kernel form, one HIP-event pair on the launch stream "
-                                "around each train (kernel + launch boundary), same observation ring, same clock regime as the blocks",
             "kernel_ms_runs": kern if len(kern) <= 8 else [min(kern), statistics.median(kern), max(kern)],
             "kernel_launches_per_run": k2,
             # for tools/summarize_prof.py: how the LAST launches of this instantiation in the run are laid out
@@ -725,6 +765,10 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
                                     "order": "block, train, block, train, ..."} if roll is None else None,
             # `achieved` counts only bytes that must cross HBM (observation write + state + outputs):
             "hbm_bytes_per_env_step": Bh, "units_per_launch": N,
+            "bytes_model": (f"B_hbm = {5 * obs_elem}WA+84A+36 (SURVEY 8d's 72WA+84A+36 minus the 32WA cache-served window reads"
+                            + ("" if obs_elem == 8 else " and 20WA of f32 observations") + ")"),
+            # what `frac` WOULD read on SURVEY 8(d)'s B (window re-reads counted as if they crossed HBM): above 1 at config 2
+            "frac_on_survey_8d_bytes": Bs * N / (kern_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
             # the window re-read of the SURVEY 8(d) formula comes from L2 / Infinity Cache, reported apart:
             "l2_read_bytes_per_env_step": l2_read, "l2_GBps": l2_read * N / (kern_ms * 1e-3) / 1e9,
             "survey_8d_bytes_per_env_step": Bs,
@@ -741,8 +785,6 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             # redraw='torch'); `roofline.kernel` above is rank 0's, `value` is the max over ranks
             "kernel_form_by_rank": forms,
             "trajectory_slots": T, "all_gather_every_steps": T,
-            "all_gather_issue": "asynchronous; chunks switch at the first step after a chunk is full, the collective is started two steps later "
-                                "(its host cost then hides behind queued steps); drained inside the timed block",
             "packed_bytes_per_rank_per_chunk": traj._nbytes,
             "gathered_bytes_per_rank_per_chunk": traj._nbytes * world,
             "value_with_all_gather": res["repeats"]["with_all_gather"]["value_median"],
@@ -780,354 +822,284 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     return res
 
 
-def two_stream_leg(args, steps: int):
-    """The headline workload as TWO contiguous shards (rank 0 / 1 of 2: the same envs, the evaluation env in the second)
-    stepped on two HIP streams.  Envs are independent, so a rollout loop that evaluates its policy per shard (a
-    double-buffered sampler, examples/double_buffered_rollout.py) lets one shard's start-up chain and launch boundary
-    overlap the other shard's store stream across steps.  Launches go through the C ABI (pre-generated actions, as in the
-    headline's kernel-interval loop).  Never part of `value`."""
-    import finenvs_amd
-
-    name, N, A, W = CONFIGS[2]
-    prices, day_id, _ = make_series(A)
-    dev = "cuda:0"
-    parts, streams = [], [torch.cuda.Stream(), torch.cuda.Stream()]
-    for r in range(2):
-        env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, rank=r, world_size=2,
-                                        redraw="device", seed=1234, obs_buffers=2)
-        n = env.num_envs
-        g = torch.Generator(device=dev).manual_seed(7 + r)
-        acts = [(torch.rand((n, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
-        env.reset()
-        parts.append((env, acts, torch.empty((n,), dtype=torch.float64, device=dev), torch.empty((n,), dtype=torch.int32, device=dev)))
-    k2 = max(min(max(steps, 20), 400), 200)  # (a 27 us step: 200 launch pairs ~ 5 ms per run)
-    times = []
-    for rep in range(4):
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for s_ in streams:
-            s_.wait_event(e0)
-        for k in range(k2 if rep else 4 * k2):  # the discarded first run also carries the GPU past its post-idle clock transient
-            for (env, acts, rew, done), s_ in zip(parts, streams):
-                rc = env._step_fn(env._handle_v, acts[k % 8].data_ptr(), env._obs_ring[k % 2].data_ptr(), rew.data_ptr(), done.data_ptr(),
-                                  s_.cuda_stream)
-        for s_ in streams:
-            torch.cuda.current_stream().wait_stream(s_)
-        e1.record()
-        torch.cuda.synchronize()
-        from finenvs_amd import _lib as _fl
-
-        _fl.check(rc)
-        if rep:
-            times.append(e0.elapsed_time(e1) / k2)
-    ms = statistics.median(times)
-    Bh = hbm_bytes(W, A, 8)
-    del parts
-    torch.cuda.empty_cache()
-    return {"workload": name, "what": "two contiguous shards (rank 0 / 1 of 2) of the same 65 536 envs on two HIP streams, C-ABI launches, "
-                                      "HIP events around the whole loop", "envs": N, "ms_per_step_all_envs": ms,
-            "value": N / ms * 1e3, "unit": "env-steps/s", "achieved_GBps": Bh * N / (ms * 1e-3) / 1e9,
-            "frac_of_8TBps": Bh * N / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "launches_per_run": 2 * k2}
 
 
-REDRAW_CONTRACT = ("eval_redraw='torch' (the class default AND the headline): the reference's own stream -- one torch.randint on the "
-                   "global generator per finished evaluation episode, decided by a per-step host read of dones[-1] (TSE:504-513; here a "
-                   "coherent host flag the kernel writes, fe_env_step_traj_notify, not a device-to-host copy); the reference-generated "
-                   "golden fixtures and its call log (rng_calls.npz) pin this mode.  eval_redraw='device' (timed as `device_redraw`, "
-                   "same block protocol): the redraws come from a Philox4x32-10 counter inside the step kernel -- THIS BUILD's contract "
-                   "(finenvs_amd/rng.py; the generator is pinned to Random123's known-answer vectors and to the oracle's restatement, "
-                   "the day SEQUENCE has no counterpart in the reference), no host synchronisation: what hipGraph capture and the fused "
-                   "rollouts need.")
 
 
-def reference_semantics_leg(args, steps: int, repeats: int = 0):
-    """What a drop-in caller of the reference's loop gets (examples/time_series/PPO_LSTM_training_SPY.py:22-30): the CLASS
-    DEFAULTS -- fresh observation / reward / done tensors per step (obs_buffers=0), redraw='torch' with the reference's
-    per-step host read of the evaluation env's done flag -- on the headline workload (config 2), timed with the headline's
-    block protocol (R blocks of exactly `steps` steps between synchronising fences after SETTLE_MS of untimed steps, median
-    block).  Never part of `value`."""
-    import finenvs_amd
-
-    name, N, A, W = CONFIGS[2]
-    prices, day_id, _ = make_series(A)
-    torch.manual_seed(1234)
-    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, device_id=0)
-    assert env.obs_buffers == 0 and env.redraw == "torch" and env.obs_dtype == torch.float64
-    g = torch.Generator(device="cuda:0").manual_seed(7)
-    actions = [(torch.rand((N, A), generator=g, device="cuda:0") * 2 - 1).float() for _ in range(8)]
-    states = env.reset()
-    for i in range(20):
-        states, _, _, _ = env.step(actions[i % 8])
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(8):
-        states, _, _, _ = env.step(actions[i % 8])
-    torch.cuda.synchronize()
-    est = (time.perf_counter() - t0) / 8
-    R = auto_repeats(repeats, steps, est)
-    for i in range(int(SETTLE_MS * 1e-3 / est)):  # the clock transient after the idle period of construction (run_workload.settle)
-        states, _, _, _ = env.step(actions[i % 8])
-    blocks = []
-    for _ in range(R):
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for i in range(steps):
-            states, rew, done, _ = env.step(actions[i % 8])
-        torch.cuda.synchronize()
-        blocks.append(time.perf_counter() - t0)
-    med = statistics.median(blocks)
-    del env, states
-    torch.cuda.empty_cache()
-    return {"workload": name, "what": "class defaults: obs_buffers=0 (fresh tensors per step), redraw='torch' (per-step host read, TSE:510), "
-                                      "f64 observations, eager env.step(actions) loop; the headline's block protocol",
-            "value": N * steps / med, "unit": "env-steps/s", "ms_per_step": med / steps * 1e3,
-            "ms_per_step_min": min(blocks) / steps * 1e3, "ms_per_step_max": max(blocks) / steps * 1e3, "steps": steps,
-            "blocks": R}
+# ------------------------------------------------------------------------------------------------------------------------
+# The contract line.  bench.py's LAST stdout line is one strict JSON object of at most LINE_CAP characters (the driver keeps
+# an 8 KB tail of stdout; round 5's 20 KB line was not parsed).  Numbers only: what each number means is DESIGN.md section 8.
+# Everything else a run measured goes to stderr as `[bench-detail] {...}` lines (and to --detail PATH as one JSON document).
+# ------------------------------------------------------------------------------------------------------------------------
+LINE_CAP = 7600
 
 
-STRONG_TOTAL_ENVS = 65536  # BASELINE.json's metric: "env-steps/sec at 64k envs, 1/2/4/8 MI355X" read as ONE 64k-env job
+def _sig(x, digits: int = 6):
+    """Floats at `digits` significant digits (the line is for reading numbers, the detail record keeps them whole)."""
+    if isinstance(x, float) and x == x and x not in (float("inf"), float("-inf")) and x != 0.0:
+        return float(f"{x:.{digits}g}")
+    return x
 
 
-def strong_scaling_leg(args, D: Dist, steps: int, warmup: int, world: int = None, rank: int = None):
-    """The STRONG-scaling reading of the metric: 65 536 envs IN TOTAL, sharded contiguously over the world (8 GPUs: 8 192 envs
-    per GPU ~ 5 us of HBM time per step -- launch-bound, where the fused / graphed forms earn their keep).  Two launch modes:
-    `eager` (env.step per step, --redraw's mode, trajectory slots written by the kernel) and `graph_k8` / `graph_k32` (rollout.GraphedRollout,
-    8 / 32 steps per hipGraph replay, redraw='device' as capture requires); with N > 1 each with and without the trajectory
-    all-gather (one packed chunk per `steps` eager steps resp. per 8-step replay, asynchronous, double-buffered).
-    `world` / `rank`: emulate one rank's shard of a larger world on THIS GPU without collectives (the N = 1 run's preview of
-    the per-GPU step time at 2 / 4 / 8 GPUs: the measured basis of DESIGN.md section 7's strong-scaling rows)."""
-    import finenvs_amd
-    from finenvs_amd.rollout import GraphedRollout
-    from finenvs_amd.trajectory import TrajectoryBuffer
+def strict(obj, bad=None, path=""):
+    """A copy of `obj` that json.dumps(..., allow_nan=False) accepts: non-finite floats become None and their paths are
+    collected in `bad` (one NaN in one leg must not cost the run its line)."""
+    if isinstance(obj, float):
+        if obj != obj or obj in (float("inf"), float("-inf")):
+            if bad is not None:
+                bad.append(path)
+            return None
+        return obj
+    if isinstance(obj, dict):
+        return {str(k): strict(v, bad, f"{path}.{k}" if path else str(k)) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return [strict(v, bad, f"{path}[{i}]") for i, v in enumerate(obj)]
+    if isinstance(obj, (str, int, bool)) or obj is None:
+        return obj
+    if hasattr(obj, "item"):  # numpy / torch scalars
+        return strict(obj.item(), bad, path)
+    return str(obj)
 
-    emulated = world is not None
-    w = world if emulated else D.world
-    r = rank if emulated else D.rank
-    dev = D.dev
-    _, _, A, W = CONFIGS[2]
-    prices, day_id, _ = make_series(A)
-    gathering = D.multi and not emulated
-    out = {"total_envs": STRONG_TOTAL_ENVS, "world": w, "emulated_on_one_gpu": emulated}
 
-    def fence(trajs=()):
-        for t in trajs:
-            t.drain()
-        if D.dist is not None and not emulated:
-            if D.backend != "nccl":
-                torch.cuda.synchronize()
-            D.barrier()
-        torch.cuda.synchronize()
+def _short(s, n):
+    s = "" if s is None else str(s)
+    return s if len(s) <= n else s[: n - 3] + "..."
 
-    def blocks_of(run_block, n_steps, trajs=(), r_blocks=None):
-        run_block()
-        fence(trajs)
-        t0 = time.perf_counter()
-        run_block()
-        fence(trajs)
-        est = (time.perf_counter() - t0) / n_steps
-        est = est if emulated else D.max_over_ranks(est)
-        R = r_blocks or auto_repeats(args.repeats, n_steps, est)
-        for _ in range(int(min(4000, SETTLE_MS * 1e-3 / max(est, 1e-9)) / n_steps) + 1):  # settle (run_workload.settle)
-            run_block()
-        ts = []
-        for _ in range(R):
-            fence(trajs)
-            t0 = time.perf_counter()
-            run_block()
-            fence(trajs)
-            dt = time.perf_counter() - t0
-            ts.append(dt if emulated else D.max_over_ranks(dt))
-        med = statistics.median(ts)
-        return {"value": STRONG_TOTAL_ENVS * n_steps / med, "us_per_step": med / n_steps * 1e6, "us_per_step_min": min(ts) / n_steps * 1e6,
-                "us_per_step_max": max(ts) / n_steps * 1e6, "blocks": R, "steps_per_block": n_steps}
 
-    # ---- eager
-    env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=STRONG_TOTAL_ENVS, rank=r, world_size=w,
-                                    device_id=D.local_rank, redraw=args.redraw, seed=1234, obs_buffers=2)
-    n = env.num_envs
-    out["envs_per_gpu"] = n
-    g = torch.Generator(device=dev).manual_seed(7 + r)
-    actions = [(torch.rand((n, A), generator=g, device=dev) * 2 - 1).float() for _ in range(8)]
-    traj = TrajectoryBuffer(steps, n, A, device=dev)
-    env.reset()
-    gather = [False]
-
-    def eager_block():
-        for i in range(steps):
-            if traj.full():
-                if gather[0]:
-                    traj.all_gather_async(defer=True)
-                else:
-                    traj.clear()
-            a, rw, d = traj.next_slot()
-            env.step(actions[i % 8], rewards_out=rw, dones_out=d, actions_out=a)
-            if i == 2:
-                traj.issue_deferred()
-
-    for _ in range(max(1, warmup // max(steps, 1))):
-        eager_block()
-    out["eager"] = {"no_all_gather": blocks_of(eager_block, steps, (traj,))}
-    kt = KernelTrain(env, actions)
-    out["eager"]["kernel_us"] = statistics.median(kt.run(400) for _ in range(3)) * 1e3
-    out["eager"]["launch"] = env.launch_info()
-    if gathering:
-        gather[0] = True
-        traj.clear()
-        eager_block()
-        out["eager"]["with_all_gather"] = blocks_of(eager_block, steps, (traj,))
-        gather[0] = False
-        fence((traj,))
-        out["eager"]["packed_bytes_per_rank_per_chunk"] = traj._nbytes
-    del env, traj, kt
-    # ---- hipGraph, K steps per replay (two graphs over two trajectory chunks: chunk i is gathered while graph 1 - i replays).
-    # K = 8 is the leg VERDICT round 4 named; K = 32 shows what a longer replay buys once a collective per replay is in the loop
-    # (its host start + latency are per replay, the steps per replay amortise them)
-    for K in (8, 32):
-        steps_g = (steps + 2 * K - 1) // (2 * K) * (2 * K)  # whole replays, both graphs equally often
-        env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=STRONG_TOTAL_ENVS, rank=r, world_size=w,
-                                        device_id=D.local_rank, redraw="device", seed=1234, obs_buffers=2)
-        trajs = [TrajectoryBuffer(K, n, A, device=dev) for _ in range(2)]
-        rolls = [GraphedRollout(env, lambda obs, k: actions[k % 8], K, trajectory=t) for t in trajs]
-        pending = [None, None]
-        gathered = [None, None]
-
-        def graph_block():
-            for j in range(steps_g // K):
-                i = j & 1
-                if pending[i] is not None:
-                    pending[i].wait()  # (stream-level for RCCL) chunk i has left before graph i overwrites it
-                    pending[i] = None
-                rolls[i].run()
-                if gather[0]:
-                    if gathered[i] is None:
-                        gathered[i] = torch.empty((D.dist.get_world_size(), trajs[i]._nbytes), dtype=torch.uint8, device=dev)
-                    pending[i] = D.dist.all_gather_into_tensor(gathered[i].view(-1), trajs[i]._packed, async_op=True)
-
-        def graph_fence_extra():
-            for i in (0, 1):
-                if pending[i] is not None:
-                    pending[i].wait()
-                    pending[i] = None
-
-        class _Drain:  # fence() drains these like a TrajectoryBuffer
-            drain = staticmethod(graph_fence_extra)
-
-        key = f"graph_k{K}"
-        out[key] = {"no_all_gather": blocks_of(graph_block, steps_g, (_Drain,))}
-        if gathering:
-            gather[0] = True
-            out[key]["with_all_gather"] = blocks_of(graph_block, steps_g, (_Drain,))
-            gather[0] = False
-            fence((_Drain,))
-            out[key]["packed_bytes_per_rank_per_chunk"] = trajs[0]._nbytes
-        del rolls, trajs, env, gathered
-    gc.collect()
-    torch.cuda.empty_cache()
+def compact_roofline(r: dict, full: bool) -> dict:
+    out = {"bound": r["bound"], "achieved": _sig(r["achieved"]), "peak": r["peak"], "unit": r["unit"], "frac": _sig(r["frac"], 4),
+           "traffic": _sig(r.get("traffic")), "traffic_source": _short(r.get("traffic_source"), 80),
+           "kernel": r.get("kernel"), "kernel_ms": _sig(r.get("kernel_ms")),
+           "hbm_bytes_per_env_step": r.get("hbm_bytes_per_env_step"), "units_per_launch": r.get("units_per_launch")}
+    if r.get("traffic_live_error"):
+        out["traffic_live_error"] = _short(r["traffic_live_error"], 140)
+    if r.get("traffic") and r.get("hbm_bytes_per_env_step"):
+        out["traffic_over_algorithmic"] = _sig(r["traffic"] / (r["hbm_bytes_per_env_step"] * r["units_per_launch"]), 4)
+    if full:
+        out.update(bytes_model=r.get("bytes_model"), survey_8d_bytes_per_env_step=r.get("survey_8d_bytes_per_env_step"),
+                   frac_on_survey_8d_bytes=_sig(r.get("frac_on_survey_8d_bytes"), 4), achieved_wall=_sig(r.get("achieved_wall")),
+                   kernel_launches_per_train=r.get("kernel_launches_per_run"),
+                   trains=(r.get("kernel_train_layout") or {}).get("repeats"))
     return out
 
 
-def device_guard_check(D: Dist):
-    """N > 1 only: the paths a one-GPU box cannot reach.  (i) fe_env_device(env) == LOCAL_RANK on every rank; (ii) a step() issued
-    while ANOTHER device is current (the reference's `device_id` argument works without torch.cuda.set_device, TSE:28, 42;
-    csrc/fe_env.hip DeviceGuard) launches on the env's device, returns tensors there, leaves the caller's current device
-    unchanged, and computes what a step with the env's device current computes.  Returns a pass / fail record (never raises)."""
-    import finenvs_amd
-
-    rec = {"local_rank": D.local_rank, "devices_visible": torch.cuda.device_count()}
-    try:
-        _, _, A, W = CONFIGS[1]
-        prices, day_id, _ = make_series(A)
-        mk = lambda: finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=1024, evaluate=True,  # noqa: E731
-                                               device_id=D.local_rank)
-        env, twin = mk(), mk()
-        rec["env_device"] = int(env._lib.fe_env_device(env._handle))
-        ok = rec["env_device"] == D.local_rank
-        a = (torch.rand((1024, A), device=D.dev) * 2 - 1).float()
-        o0, r0, d0, _ = twin.step(a)
-        if rec["devices_visible"] > 1:
-            other = (D.local_rank + 1) % rec["devices_visible"]
-            with torch.cuda.device(other):
-                before = torch.cuda.current_device()
-                o1, r1, d1, _ = env.step(a)
-                after = torch.cuda.current_device()
-            rec.update(other_device=other, current_device_before=before, current_device_after=after,
-                       outputs_on=str(o1.device), current_device_restored=torch.cuda.current_device() == D.local_rank)
-            torch.cuda.synchronize(D.dev)
-            same = bool(torch.equal(o0, o1) and torch.equal(r0, r1) and torch.equal(d0, d1))
-            rec["same_result_as_with_own_device_current"] = same
-            ok = ok and before == other and after == other and str(o1.device) == D.dev and same and rec["current_device_restored"]
-        else:
-            rec["other_device"] = None
-            rec["note"] = "one device visible: the cross-device half needs the multi-GPU node"
-        rec["pass"] = bool(ok)
-    except Exception as exc:  # noqa: BLE001
-        rec["pass"] = False
-        rec["error"] = f"{type(exc).__name__}: {exc}"
-    return rec
+def compact_multi_gpu(m: dict, strong, guard) -> dict:
+    """Numbers only (task 8): what the first SCALE record needs to explain itself."""
+    out = {k: _sig(m.get(k)) for k in ("ranks_seen", "collective_backend", "kernel_form_by_rank", "trajectory_slots",
+                                       "packed_bytes_per_rank_per_chunk", "gather_only_ms", "gather_only_inbound_GBps_per_gpu",
+                                       "exposed_ms_per_step")}
+    out["with_all_gather"] = _sig(m.get("value_with_all_gather"))
+    out["no_all_gather"] = _sig(m.get("value_no_all_gather"))
+    p = m.get("prediction") or {}
+    out["predicted_gather_only_ms"] = [_sig(x, 4) for x in p.get("predicted_gather_only_ms", [])]
+    rc = m.get("rccl") or {}
+    out["rccl"] = _short("; ".join((rc.get("version") or [])[:1] + (rc.get("algorithm_protocol") or [])[:1]), 120) if rc else None
+    out["device_guard"] = None if guard is None else {"pass": bool(guard.get("pass")), **({"error": _short(guard["error"], 100)} if guard.get("error") else {})}
+    if strong is not None:
+        out["strong"] = compact_strong(strong)
+    return out
 
 
-def fused_rollout_legs(args):
-    """SURVEY 8f.2 legs, reported beside the headline (never part of `value`): K env steps per launch with the policy
-    evaluated in the kernel, at the headline's 65 536 envs x 1 asset.  The observation is never written to HBM, so these
-    are not HBM-roofline numbers: the MLP / LSTM legs report the f32 MFMA rate of their contractions instead."""
-    import finenvs_amd
-    from finenvs_amd.rollout import FusedLinearRollout, FusedLSTMRollout, FusedMLPRollout
+def compact_strong(st: dict) -> dict:
+    """The strong-scaling reading (65 536 envs IN TOTAL): env-steps/s per launch mode; at N = 1 the per-GPU step of a 2 / 4 / 8-GPU
+    world emulated on this GPU (us per step, one column per world)."""
+    if "error" in st:
+        return {"error": _short(st["error"], 120)}
+    out = {"total_envs": st.get("total_envs"), "world": st.get("world"), "envs_per_gpu": st.get("envs_per_gpu")}
+    for mode in ("eager", "graph_k8", "graph_k32"):
+        m = st.get(mode)
+        if not m:
+            continue
+        out[mode] = {k: _sig(m[k]["value"]) for k in ("no_all_gather", "with_all_gather") if k in m}
+    prev = st.get("shard_preview")
+    if prev:
+        worlds = [st] + list(prev)
+        out["us_per_step_at_world"] = {"worlds": [w.get("world") for w in worlds], "emulated_on_one_gpu": True,
+                                       **{mode: [_sig(w[mode]["no_all_gather"]["us_per_step"], 4) if mode in w else None for w in worlds]
+                                          for mode in ("eager", "graph_k8", "graph_k32")},
+                                       "kernel_us": [_sig(w["eager"].get("kernel_us"), 4) if "eager" in w else None for w in worlds]}
+    return out
 
-    _, N, A, _ = CONFIGS[2]
-    prices, day_id, _ = make_series(A)
-    g = torch.Generator().manual_seed(0)
+
+def compact_line(detail: dict) -> dict:
+    """The driver's line from the full record: the contract keys, `roofline`, `cpu_baseline`, `multi_gpu` (N > 1), and one short
+    summary per extra workload / leg.  No prose (DESIGN.md section 8 says what every key means)."""
+    head = detail["headline"]
+    hr = head["roofline"]
+    unfinished = list(detail.get("unfinished") or [])
+    line = {
+        "metric": "env-steps/sec", "value": head["value"], "unit": "env-steps/s", "n_gpus": detail["n_gpus"],
+        "steps": detail["steps"], "warmup": head["warmup"], "ms_per_step": head["ms_per_step"], "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": detail["dtype"], "data": "synthetic",
+        "config": {"workload": head["workload"], "envs_per_gpu": head["envs_per_gpu"], "num_assets": head["num_assets"],
+                   "window": head["window"], "obs_buffers": head["obs_buffers"], "obs_dtype": detail["dtype"],
+                   "eval_redraw": detail["eval_redraw"], "launch_mode": head["launch_mode"],
+                   "settle_steps": head["settle_steps"], "untimed_steps_before_value": head.get("untimed_steps_before_value"),
+                   "timed_blocks": next(iter(head["repeats"].values()))["blocks"] if head.get("repeats") else None,
+                   "ms_per_step_min_max": [_sig(next(iter(head["repeats"].values()))[k]) for k in ("ms_per_step_min", "ms_per_step_max")]
+                   if head.get("repeats") else None},
+        "roofline": compact_roofline(hr, full=True),
+        "cpu_baseline": None,
+    }
+    cb = head.get("cpu_baseline")
+    if cb:
+        line["cpu_baseline"] = {"value": _sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                "sample": _short(cb["sample"], 120), "value_1thread": _sig(cb.get("value_1thread")),
+                                "cpu_model": _short(cb.get("cpu_model"), 60),
+                                "reference_quoted": {k: (cb.get("reference_quoted") or {}).get(k) for k in ("value", "cores")}}
+    aa = head.get("as_allocated")
+    if aa:
+        line["as_allocated"] = {"value": _sig(aa["value"]), "ms_per_step": _sig(aa["ms_per_step"]), "kernel_ms": _sig(aa["kernel_ms"]),
+                                "frac": _sig(aa["frac_of_8TBps_kernel"], 4), "ring_changed_by_audition": aa.get("ring_changed_by_audition")}
+    if head.get("multi_gpu"):
+        line["multi_gpu"] = compact_multi_gpu(head["multi_gpu"], detail.get("strong_scaling"), detail.get("device_guard"))
+    extras = []
+    for e in detail.get("extra_configs") or []:
+        if "error" in e:
+            extras.append({"config": e.get("config"), "workload": e.get("workload"), "error": _short(e["error"], 120)})
+            continue
+        x = {"config": e["config"], "workload": e["workload"], "value": _sig(e["value"]), "ms_per_step": _sig(e["ms_per_step"]),
+             "envs_per_gpu": e["envs_per_gpu"], "obs_buffers": e["obs_buffers"], "roofline": compact_roofline(e["roofline"], full=False)}
+        if e.get("as_allocated"):
+            x["as_allocated"] = {"value": _sig(e["as_allocated"]["value"]), "frac": _sig(e["as_allocated"]["frac_of_8TBps_kernel"], 4)}
+        if e.get("multi_gpu"):
+            x["multi_gpu"] = compact_multi_gpu(e["multi_gpu"], None, None)
+        extras.append(x)
+    line["extra_configs"] = extras
     legs = []
-    for form, W, K in (("linear_table", 64, 32), ("mlp_h64", 64, 32), ("lstm_h128", 4, 8), ("lstm_h1024", 4, 2)):
-        try:
-            env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device",  # (in-kernel redraws)
-                                            seed=1234, obs_buffers=1)
-            flop = 0.0
-            if form == "linear_table":
-                roll = FusedLinearRollout(env, torch.randn((W, 5), dtype=torch.float64, generator=g) * 2, 0.0, form="table")
-                policy = "clamp(<window, weights (W, 5)>), log-return part precomputed as an indicator table"
-            elif form == "mlp_h64":
-                H = 64
-                roll = FusedMLPRollout(env, torch.randn((5 * W, H), generator=g) * (8.0 / W ** 0.5), torch.randn(H, generator=g) * 0.3,
-                                       torch.randn(H, generator=g) / H ** 0.5, 0.0)
-                flop = 2.0 * N * A * (4 * W) * H
-                policy = "Linear(5W, 64) -> ELU -> Linear(64, 1), first layer on v_mfma_f32_32x32x2_f32"
+    for name, leg in (detail.get("legs") or {}).items():
+        if leg is None:
+            continue
+        if "error" in leg:
+            legs.append({"leg": name, "error": _short(leg["error"], 100)})
+            continue
+        x = {"leg": name, "value": _sig(leg.get("value")), "ms_per_step": _sig(leg.get("ms_per_step"))}
+        if leg.get("frac") is not None:
+            x["frac"] = _sig(leg["frac"], 4)
+        if leg.get("bound"):
+            x["bound"] = leg["bound"]
+        legs.append(x)
+    line["legs"] = legs
+    if detail.get("strong_scaling") is not None and not head.get("multi_gpu"):
+        line["strong_scaling"] = compact_strong(detail["strong_scaling"])
+    if unfinished:
+        line["unfinished"] = unfinished
+    return line
+
+
+def render_line(detail: dict) -> str:
+    """compact_line -> one strict JSON line of at most LINE_CAP characters.  Optional sections are dropped (named in `dropped`)
+    rather than ever exceeding the cap; the contract keys, `roofline` and `cpu_baseline` always stay."""
+    bad = []
+    line = strict(compact_line(detail), bad)
+    if bad:
+        line["nonfinite_set_to_null"] = bad[:12]
+    dropped = []
+    for victim in (None, "strong_scaling", "legs", "as_allocated", "extra_configs", "multi_gpu"):
+        if victim is not None:
+            if victim not in line:
+                continue
+            if victim == "multi_gpu":  # keep its numbers, lose the nested legs
+                line["multi_gpu"] = {k: v for k, v in line["multi_gpu"].items() if not isinstance(v, (dict, list))}
             else:
-                H = int(form.split("_h")[1])
-                torch.manual_seed(0)
-                lstm, lin = torch.nn.LSTM(5, H, batch_first=True), torch.nn.Linear(H, 1)
-                with torch.no_grad():
-                    lstm.weight_ih_l0[:, :4].mul_(6.0 * H ** 0.5)
-                roll = FusedLSTMRollout.from_modules(env, lstm, lin)
-                flop = 2.0 * N * A * 4 * H * (8 * W + H * (W - 1))
-                policy = (f"the reference's actor: LSTM(5, {H}) over the W rows -> Linear({H}, 1) -> tanh, gates on v_mfma_f32_32x32x2_f32"
-                          + (", recurrent weights streamed from L2 (the reference example's hidden_dim)" if H > 128 else ", recurrent weights in registers"))
-            roll.run(K, record_actions=True)
-            times = []
-            for _ in range(3):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                torch.cuda.synchronize()
-                e0.record()
-                roll.run(K, record_actions=True)
-                e1.record()
-                torch.cuda.synchronize()
-                times.append(e0.elapsed_time(e1) / K)
-            ms = statistics.median(times)
-            leg = {"form": form, "policy": policy, "envs": N, "num_assets": A, "window": W, "steps_per_launch": K,
-                   "us_per_step": round(ms * 1e3, 2), "value": round(N / ms * 1e3, 1), "unit": "env-steps/s"}
-            if flop:  # MFMA-bound legs: the contraction's FLOPs as executed against the dense f32 MFMA peak (256 CUs x 256 FLOP/cycle x 2.4 GHz)
-                leg["mfma_f32_tflops"] = round(flop / ms / 1e9, 1)
-                leg["mfma_f32_peak_tflops"] = 157.3
-                leg["roofline"] = {"bound": "mfma", "achieved": round(flop / ms / 1e9, 1), "peak": 157.3, "unit": "TFLOP/s",
-                                   "frac": round(flop / ms / 1e9 / 157.3, 3), "traffic": None,
-                                   "note": "launch time from HIP events around K-step launches (policy + accounting); the f32-input MFMA "
-                                           "shares the vector ALUs with the activations (SQ_VALU_MFMA_COEXEC_CYCLES = 0, profiles/r02g_lstm_summary.md)"}
-            legs.append(leg)
-            del env, roll
-            torch.cuda.empty_cache()
-        except Exception as exc:  # noqa: BLE001
-            legs.append({"form": form, "error": f"{type(exc).__name__}: {exc}"})
-    return legs
+                del line[victim]
+            dropped.append(victim)
+            line["dropped_for_size"] = dropped
+        s = json.dumps(line, allow_nan=False, separators=(", ", ": "))
+        if len(s) <= LINE_CAP:
+            return s
+    return s[:LINE_CAP]  # unreachable with the sections above gone (the core is ~2.5 KB)
+
+
+def emit_detail(tag: str, obj) -> None:
+    """Full records go to stderr, one JSON line each (the driver keeps stderr beside stdout); never to stdout."""
+    try:
+        print(f"[bench-detail] {json.dumps({tag: strict(obj)}, allow_nan=False)}", file=sys.stderr, flush=True)
+    except Exception as exc:  # noqa: BLE001
+        print(f"[bench-detail] {tag}: not serialisable ({type(exc).__name__}: {exc})", file=sys.stderr, flush=True)
+
+
+def leg_summary(name: str, leg):
+    """value / ms_per_step / frac of one extra leg's detail record (the keys compact_line reads)."""
+    if leg is None:
+        return None
+    if "error" in leg:
+        return {"error": leg["error"]}
+    if name == "device_redraw":
+        return {"value": leg["value"], "ms_per_step": leg["ms_per_step"], "frac": leg.get("frac"), "bound": "hbm"}
+    if name == "reference_semantics":
+        return {"value": leg["value"], "ms_per_step": leg["ms_per_step"],
+                "frac": hbm_bytes(64, 1, 8) * 65536 / (leg["ms_per_step"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, "bound": "hbm"}
+    if name == "two_streams":
+        return {"value": leg["value"], "ms_per_step": leg["ms_per_step_all_envs"], "frac": leg["frac_of_8TBps"], "bound": "hbm"}
+    # fused rollouts: MFMA-bound where there is a contraction, otherwise no roofline figure
+    r = leg.get("roofline")
+    return {"value": leg["value"], "ms_per_step": leg["us_per_step"] * 1e-3, "frac": r["frac"] if r else None, "bound": "mfma" if r else None}
+
+
+class LineGuard:
+    """Owns the one stdout line.  print_once() writes it exactly once; arm(seconds) starts a watchdog that -- if the legs after
+    the headline are not through in time (a hung collective, a hung kernel) -- marks what is unfinished, prints the line this rank
+    has, and ends the process with exit code 3 WITHOUT waiting for the GPU (no restart, no re-exec).  Ranks other than 0 leave a few
+    seconds later, so that the launcher does not tear rank 0 down before its line is out."""
+
+    EXIT_CODE = 3
+
+    def __init__(self, result_out, detail: dict, rank: int, detail_path=None):
+        import threading
+
+        self.out, self.detail, self.rank, self.detail_path = result_out, detail, rank, detail_path
+        self.lock = threading.Lock()
+        self.printed = False
+        self.timer = None
+        self.current = ["(nothing)"]  # the leg in progress, for the watchdog's record
+
+    def print_once(self):
+        with self.lock:
+            if self.printed:
+                return
+            s = None
+            for _ in range(3):  # (the watchdog may render while the main thread is still adding a leg's record)
+                try:
+                    s = render_line(self.detail)
+                    break
+                except Exception as exc:  # noqa: BLE001
+                    print(f"bench.py: rendering the line failed ({type(exc).__name__}: {exc}); retrying", file=sys.stderr, flush=True)
+                    time.sleep(0.05)
+            if s is None:  # the headline alone
+                core = {k: self.detail[k] for k in ("n_gpus", "steps", "dtype", "eval_redraw", "headline")}
+                s = render_line(dict(core, unfinished=["(record could not be rendered in full)"]))
+            self.printed = True
+            if self.rank == 0:
+                sys.stderr.flush()
+                if self.detail_path:
+                    try:
+                        with open(self.detail_path, "w") as f:
+                            json.dump(strict(self.detail), f, allow_nan=False)
+                    except Exception as exc:  # noqa: BLE001
+                        print(f"bench.py: --detail {self.detail_path}: {type(exc).__name__}: {exc}", file=sys.stderr)
+                print(s, file=self.out, flush=True)
+
+    def arm(self, seconds: float):
+        import threading
+
+        def give_up():
+            msg = f"watchdog: `{self.current[0]}` not finished after {seconds:g} s; line printed without it, exit code {self.EXIT_CODE}"
+            print(f"bench.py rank {self.rank}: {msg}", file=sys.stderr, flush=True)
+            self.detail.setdefault("unfinished", []).append(self.current[0])
+            self.detail["watchdog"] = msg
+            self.print_once()
+            if self.rank != 0:
+                time.sleep(4.0)
+            os._exit(self.EXIT_CODE)
+
+        self.timer = threading.Timer(seconds, give_up)
+        self.timer.daemon = True
+        self.timer.start()
+
+    def disarm(self):
+        if self.timer is not None:
+            self.timer.cancel()
 
 
 def main():
@@ -1138,7 +1110,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=sorted(CONFIGS))
     ap.add_argument("--repeats", type=int, default=0, help="timed K-step blocks (0 = auto: ~0.15 s of timed work, 5..40)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs legs")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs and the extra legs")
     ap.add_argument("--redraw", default="torch", choices=["torch", "device"],
                     help="the evaluation env's day redraw: 'torch' = the reference's RNG stream and per-step host read (class default, "
                          "pinned by the reference's fixtures); 'device' = in-kernel Philox (timed as the `device_redraw` leg by default)")
@@ -1146,6 +1118,7 @@ def main():
     ap.add_argument("--graph", action="store_true", help="replay the 8-action ring as one hipGraph per 8 steps")
     ap.add_argument("--no-audition", action="store_true", help="take the observation ring as allocated (no placement audition)")
     ap.add_argument("--no-pmc", action="store_true", help="do not measure roofline.traffic with rocprofv3 child passes")
+    ap.add_argument("--detail", default=None, metavar="PATH", help="also write the full record (everything stderr's [bench-detail] lines carry) as one JSON document")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.pmc_child:
@@ -1157,172 +1130,136 @@ def main():
     sys.stdout.flush()
     result_out = os.fdopen(os.dup(1), "w")
     os.dup2(2, 1)
+    sys.modules.setdefault("bench", sys.modules[__name__])  # tools/bench_legs.py does `from bench import ...`: this module, not a second copy
 
     if args.graph and args.redraw != "device":
         print("bench.py --graph: hipGraph capture cannot contain the per-step host read of redraw='torch' -> redraw='device'", file=sys.stderr)
         args.redraw = "device"
     D = Dist(args)
-    head = run_workload(args.config, args, D, args.steps, args.warmup, args.repeats,
-                        with_cpu=(not args.no_cpu and not D.multi))
+    t_start = time.perf_counter()
+
+    def note(msg):
+        if D.rank == 0:
+            print(f"[bench {time.perf_counter() - t_start:6.1f} s] {msg}", file=sys.stderr, flush=True)
+
+    # ---- 1. the headline (+ cpu_baseline on the plain N = 1 run): nothing else has touched the GPU yet
+    head = run_workload(args.config, args, D, args.steps, args.warmup, args.repeats, with_cpu=(not args.no_cpu and not D.multi))
     if "error" in head:
         sys.exit(f"bench.py: headline workload failed: {head['error']}")
+    detail = {"n_gpus": D.world, "steps": args.steps, "dtype": "f32" if args.obs_f32 else "f64", "eval_redraw": args.redraw,
+              "headline": head, "extra_configs": [], "legs": {}, "strong_scaling": None, "device_guard": None, "unfinished": []}
+    guard = LineGuard(result_out, detail, D.rank, args.detail)
+    emit_detail("headline", head)
+    note(f"headline: {head['value']:.4g} env-steps/s, kernel {head['roofline']['kernel_ms'] * 1e3:.2f} us, frac {head['roofline']['frac']:.3f}")
+
+    # ---- 2. from here on a watchdog owns the line: whatever hangs below costs its own leg, not `value` / roofline / cpu_baseline
+    guard.arm(WATCHDOG_S)
+
+    def leg(name):
+        guard.current[0] = name
+        note(f"{name} ...")
+
     def measure_traffic(res, config):
         """roofline.traffic measured live (the workload's env is gone by now: the children have the card to themselves)."""
         if D.multi or args.no_pmc or args.graph or "error" in res:
             return
+        leg(f"pmc_traffic_config{config}")
+        # the workload's tensors died with run_workload's frame, AFTER its own empty_cache(): without this the caching allocator of
+        # THIS process still holds them (config 4: 154 GB) and the child cannot allocate its own (round 5's "child exited with 1")
+        gc.collect()
+        torch.cuda.empty_cache()
         t, src = live_pmc_traffic(config, args.obs_f32, args.redraw, args.no_audition)
         if t is not None:
             res["roofline"]["traffic"], res["roofline"]["traffic_source"] = t, src
-        else:
-            res["roofline"]["traffic_source"] = f"{res['roofline']['traffic_source']} (live PMC pass unavailable: {src})"
+        else:  # the committed counter passes stay in `traffic` (named in traffic_source); the live attempt's cause beside them
+            res["roofline"]["traffic_live_error"] = src
+            note(f"live PMC pass of config {config} failed: {src}")
 
     measure_traffic(head, args.config)
-    extras = []
-    if not args.no_extra and not args.graph and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
+    want_extra = not args.no_extra and not args.graph and os.environ.get("FE_BENCH_NO_EXTRA") != "1"
+    if os.environ.get("FE_BENCH_HANG_LEG") == "1":  # rehearsal of the watchdog (tests only): a leg that never returns
+        leg("rehearsal_hang")
+        time.sleep(1e6)
+    if want_extra:
         # N = 1: configs 3, 4 and the per-GPU shard of config 5 (524 288 envs: the N = 1 anchor of the weak-scaling curve
         # the 8-GPU run continues); N > 1: the config-5 shard
-        wanted = ([3, 4, 5] if not D.multi else [5])
-        for c in wanted:
+        for c in ([3, 4, 5] if not D.multi else [5]):
             if c == args.config:
                 continue
-            k = min(args.steps, 20)
+            leg(f"config{c}")
             try:
-                extras.append(run_workload(c, args, D, k, min(args.warmup, 5), 3, with_cpu=False))
-                measure_traffic(extras[-1], c)
+                e = run_workload(c, args, D, min(args.steps, 20), min(args.warmup, 5), 3, with_cpu=False)
+                detail["extra_configs"].append(e)
+                measure_traffic(e, c)
+                emit_detail(f"config{c}", e)
             except Exception as exc:  # noqa: BLE001
-                extras.append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
+                detail["extra_configs"].append({"workload": CONFIGS[c][0], "config": c, "error": f"{type(exc).__name__}: {exc}"})
                 break
-
-    late = {}  # legs measured after the headline and extra_configs: build_line() reads what is there
-
-    def build_line():
-        strong, guard = late.get("strong"), late.get("guard")
-        fused, refsem, two_streams, devred = (late.get(k) for k in ("fused", "refsem", "two_streams", "devred"))
-        return {
-            "metric": "env-steps/sec",
-            "value": head["value"],
-            "unit": "env-steps/s",
-            "n_gpus": D.world,
-            "steps": args.steps,
-            "warmup": head["warmup"],
-            "ms_per_step": head["ms_per_step"],
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32" if args.obs_f32 else "f64",
-            "data": "synthetic",
-            "config": {"workload": head["workload"], "envs_per_gpu": head["envs_per_gpu"],
-                       "num_assets": head["num_assets"], "window": head["window"],
-                       "obs_buffers": head["obs_buffers"], "obs_ring_audition": head["obs_ring_audition"],
-                       "obs_ring_audition_bound": {"extra_candidates": AUDITION_EXTRA, "budget_bytes": AUDITION_BUDGET},
-                       "eval_redraw": args.redraw, "redraw_contract": REDRAW_CONTRACT,
-                       "launch_mode": head["launch_mode"], "launch": head["launch"],
-                       "untimed_steps_before_timing": {"warmup": head["warmup"], "settle": head["settle_steps"],
-                                                       "why": f"{SETTLE_MS:g} ms of steps straight before each timed phase: after an idle period the GPU "
-                                                              "runs the same kernel 15 - 25 % slower for ~10 ms (clock transient, "
-                                                              "profiles/r04_microbench/idle_transient.txt)"},
-                       "timed_region": f"STEADY STATE: beyond --warmup {head['warmup']}, {head['settle_steps']} untimed steps ({SETTLE_MS:g} ms of GPU time) "
-                                       "run straight before the timed phase, because after an idle period this pool's GPUs run the same kernel "
-                                       "15 - 25 % slower for ~10 ms and a rollout runs for minutes (untimed_steps_before_timing).  Then: median of R blocks of "
-                                       "exactly `steps` steps, each between (drain + synchronize + barrier + synchronize) fences, MAX over ranks "
-                                       "per block; after each block one train of back-to-back C-ABI launches of the same kernel form gives "
-                                       "`roofline.kernel_ms` (same ring, same clock regime).  A block of --steps 20 at 64k envs is ~0.6 ms: the "
-                                       "idle-GPU start of every block, the closing fence and env.step's Python make `ms_per_step` a few per cent "
-                                       "longer than `roofline.kernel_ms`"},
-            # the un-auditioned regime beside the headline: same loop, same fences, the ring as the allocator handed it out
-            "as_allocated": head["as_allocated"],
-            "repeats": head["repeats"],
-            "roofline": head["roofline"],
-            "cpu_baseline": head.get("cpu_baseline"),
-            "multi_gpu": (dict(head["multi_gpu"], strong=strong, device_guard=guard) if head.get("multi_gpu") else None),
-            "strong_scaling": strong,
-            "device_redraw": devred,
-            "extra_configs": [{k: v for k, v in e.items() if k != "cpu_baseline"} for e in extras],
-            "fused_rollouts": fused,
-            "reference_semantics": refsem,
-            "two_streams": two_streams,
-        }
 
     # the strong-scaling reading of the metric (64k envs IN TOTAL over the world) beside the weak one; at N = 1 also the
     # per-GPU shard of a 2 / 4 / 8-GPU world emulated on this GPU (no collectives): the measured basis of DESIGN.md section 7
-    strong = guard = None
-    want_strong = not args.no_extra and not args.graph and not args.obs_f32 and args.config == 2
-    watchdog = None
-    if D.multi:
-        # The strong-scaling leg and the DeviceGuard check have never run with more than one RCCL rank before the driver's
-        # scaling bench.  They must not be able to cost the run its line: if they are not through after WATCHDOG_S, EVERY
-        # rank gives up at about the same time -- rank 0 prints the line it has (headline + extra_configs, the unfinished
-        # legs marked) and all ranks leave with exit code 0 without waiting for a collective that will not come.
-        import threading
+    if not args.no_extra and not args.graph and not args.obs_f32 and args.config == 2:
+        sys.path.insert(0, os.path.join(REPO, "tools"))
+        import bench_legs as L
 
-        def give_up():
-            late.setdefault("strong", {"error": f"not finished after {WATCHDOG_S:g} s (watchdog): leg abandoned"})
-            late.setdefault("guard", {"pass": False, "error": f"not finished after {WATCHDOG_S:g} s (watchdog)"})
-            if D.rank == 0:
-                sys.stderr.flush()
-                print(json.dumps(build_line()), file=result_out, flush=True)
-            os._exit(0)
-
-        watchdog = threading.Timer(WATCHDOG_S, give_up)
-        watchdog.daemon = True
-    if want_strong:
-        if watchdog is not None:
-            watchdog.start()
+        leg("strong_scaling")
         try:
             if os.environ.get("FE_BENCH_HANG_STRONG") == "1":  # rehearsal of the watchdog (tests only)
                 time.sleep(1e6)
-            strong = strong_scaling_leg(args, D, args.steps, args.warmup)
+            strong = L.strong_scaling_leg(args, D, args.steps, args.warmup)
             if not D.multi:
-                strong["shard_preview"] = [strong_scaling_leg(args, D, args.steps, args.warmup, world=w_, rank=w_ - 1) for w_ in (2, 4, 8)]
-        except Exception as exc:  # noqa: BLE001  (the same code runs on every rank: an exception here is raised on all of them)
+                strong["shard_preview"] = [L.strong_scaling_leg(args, D, args.steps, args.warmup, world=w_, rank=w_ - 1) for w_ in (2, 4, 8)]
+        except Exception as exc:  # noqa: BLE001  (a per-rank failure leaves the other ranks in a collective: the watchdog ends that)
             strong = {"error": f"{type(exc).__name__}: {exc}"}
-        late["strong"] = strong
-    if D.multi:
-        if watchdog is not None and not watchdog.is_alive():
-            watchdog.start()
-        try:
-            mine = device_guard_check(D)
-            recs = [None] * D.dist.get_world_size()
-            D.dist.all_gather_object(recs, mine)
-            guard = {"pass": all(bool(r_ and r_.get("pass")) for r_ in recs), "ranks": recs,
-                     "what": "fe_env_device(env) == LOCAL_RANK on every rank; a step() issued with ANOTHER device current launches on the "
-                             "env's device, leaves the caller's current device unchanged and equals the step of a twin env (TSE:28, 42; DeviceGuard)"}
-        except Exception as exc:  # noqa: BLE001
-            guard = {"pass": False, "error": f"{type(exc).__name__}: {exc}"}
-        late["guard"] = guard
-        if watchdog is not None:
-            watchdog.cancel()
-
-    fused = refsem = two_streams = devred = None
-    if not D.multi and not args.no_extra and not args.graph and not args.obs_f32 and os.environ.get("FE_BENCH_NO_EXTRA") != "1":
-        if args.redraw == "torch" and args.config == 2:
-            # the build's own redraw contract on the same workload, the same ring policy, the same block protocol
+        detail["strong_scaling"] = strong
+        emit_detail("strong_scaling", strong)
+        if D.multi:
+            leg("device_guard")
             try:
-                dr = run_workload(2, args, D, args.steps, args.warmup, args.repeats, with_cpu=False, redraw="device")
-                devred = {k: dr[k] for k in ("workload", "value", "ms_per_step", "steps", "warmup", "settle_steps", "repeats", "as_allocated", "error") if k in dr}
-                if "roofline" in dr:
-                    devred.update(kernel=dr["roofline"]["kernel"], kernel_ms=dr["roofline"]["kernel_ms"], frac=dr["roofline"]["frac"])
-                devred["what"] = "the headline workload with eval_redraw='device' (in-kernel Philox redraws, no host flag), same ring, fences and block protocol as `value`"
+                mine = L.device_guard_check(D)
+                recs = [None] * D.dist.get_world_size()
+                D.dist.all_gather_object(recs, mine)
+                dg = {"pass": all(bool(r_ and r_.get("pass")) for r_ in recs), "ranks": recs}
             except Exception as exc:  # noqa: BLE001
-                devred = {"error": f"{type(exc).__name__}: {exc}"}
-        fused = fused_rollout_legs(args)
-        try:
-            refsem = reference_semantics_leg(args, args.steps, args.repeats)
-        except Exception as exc:  # noqa: BLE001
-            refsem = {"error": f"{type(exc).__name__}: {exc}"}
-        try:
-            two_streams = two_stream_leg(args, args.steps)
-        except Exception as exc:  # noqa: BLE001
-            two_streams = {"error": f"{type(exc).__name__}: {exc}"}
-    late.update(fused=fused, refsem=refsem, two_streams=two_streams, devred=devred)
+                dg = {"pass": False, "error": f"{type(exc).__name__}: {exc}"}
+            detail["device_guard"] = dg
+            emit_detail("device_guard", dg)
+        elif want_extra:
+            legs = detail["legs"]
 
-    out = build_line() if D.rank == 0 else None
+            def run_leg(name, fn):
+                leg(name)
+                try:
+                    rec = fn()
+                except Exception as exc:  # noqa: BLE001
+                    rec = {"error": f"{type(exc).__name__}: {exc}"}
+                emit_detail(name, rec)
+                detail.setdefault("legs_detail", {})[name] = rec
+                return rec
+
+            if args.redraw == "torch":
+                # the build's own redraw contract on the same workload, the same ring policy, the same block protocol
+                def devred():
+                    dr = run_workload(2, args, D, args.steps, args.warmup, args.repeats, with_cpu=False, redraw="device")
+                    if "error" not in dr:
+                        dr.update(kernel=dr["roofline"]["kernel"], kernel_ms=dr["roofline"]["kernel_ms"], frac=dr["roofline"]["frac"])
+                    return dr
+
+                rec = run_leg("device_redraw", devred)
+                legs["device_redraw"] = leg_summary("device_redraw", rec)
+            fused = run_leg("fused_rollouts", lambda: {"legs": L.fused_rollout_legs(args)})
+            for f_ in fused.get("legs", []):
+                legs["fused_" + f_["form"]] = leg_summary("fused", f_)
+            legs["reference_semantics"] = leg_summary("reference_semantics", run_leg("reference_semantics", lambda: L.reference_semantics_leg(args, args.steps, args.repeats)))
+            legs["two_streams"] = leg_summary("two_streams", run_leg("two_streams", lambda: L.two_stream_leg(args, args.steps)))
+
+    guard.current[0] = "teardown"
     if D.dist is not None:
         D.barrier()
         D.dist.destroy_process_group()
-    if out is not None:  # the very last thing this process writes: nothing (process-group teardown chatter) follows it
-        sys.stderr.flush()
-        print(json.dumps(out), file=result_out, flush=True)
+    guard.disarm()
+    note("done")
+    guard.print_once()  # the very last thing this process writes to stdout: nothing (process-group teardown chatter) follows it
 
 
 if __name__ == "__main__":

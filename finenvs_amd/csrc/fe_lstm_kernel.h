@@ -507,7 +507,7 @@ __global__ __launch_bounds__(kLstmBlock, 2) void fe_rollout_lstm_big_kernel(cons
 // both sides are one coalesced KiB per wavefront -- and the launch boundary is the exchange of h.  A last launch per env
 // step reduces h_W to the action and runs the accounting (one lane per sleeve).  Same k order, same activations, same
 // cell update: the same oracle function, bit for bit.  The floor is the accumulator chain itself: H/2 + 4 DEPENDENT MFMAs
-// per time step at 64 cycles each (tools/mfma_probe.hip) = 15 us at H = 1024; the launch reaches 25 - 30 us: its L2 is
+// per time step at 64 cycles each (measured in round 2 with a dependent-MFMA probe, NOTES.md) = 15 us at H = 1024; the launch reaches 25 - 30 us: its L2 is
 // cold, so the row tile's weights are staged through LDS by the whole workgroup and h arrives 16 k groups ahead.
 struct LstmSplitArgs {
     LstmArgs a;          // weights (whh fragment-major), descriptors, outputs of step k (pointers already offset)
@@ -585,7 +585,7 @@ __global__ __launch_bounds__(kBlock) void fe_lstm_split_gates_kernel(const Param
     }
     if (t > 0) {
         float4 wnext = s_w[lane];  // the A fragment is read from LDS one k group ahead of its MFMAs (a dependent MFMA can
-                                   // issue every 64 cycles, tools/mfma_probe.hip: nothing may wait in between)
+                                   // issue every 64 cycles, measured in round 2, NOTES.md: nothing may wait in between)
 #pragma unroll 1
         for (int g0 = 0; g0 < NG; g0 += AHEAD) {
 #pragma unroll

@@ -328,6 +328,8 @@ class TimeSeriesEnv:
         # the reference's share tensors become f64 at the first step() with float64 actions and stay f64 (step()): from then
         # on every step goes through fe_env_step_promoted
         self.shares_promoted = False
+        self._mirrors = {}                  # promoted f64 share tensors handed out since the last launch (_promoted_mirror)
+        self._terminated_view_out = False   # the bool view of the termination flags was handed out (_sync_public_views)
         self._flag = None
         self._flag_seq = 0
         self.flag_timeout_s = 60.0  # how long step() waits for the kernel's word before it synchronises and gives up
@@ -365,7 +367,7 @@ class TimeSeriesEnv:
 
     def audition_ring(self, extra: int = 2, budget_bytes: Optional[int] = None, min_gain: float = 0.03) -> None:
         """Ring mode only (also what ``obs_audition=`` runs at construction).  HBM write bandwidth on MI355X depends on where a buffer lies (the same store kernel runs
-        5.7 ... 6.5 TB/s on different 20 GB allocations, reproducibly per buffer; tools/placement.hip, DESIGN.md
+        5.7 ... 6.5 TB/s on different 20 GB allocations, reproducibly per buffer; profiles/r02_microbench/placement_20g.txt, DESIGN.md
         section 4), and the step kernel is bound by exactly that.  So: allocate up to ``extra`` more candidate
         buffers than the ring needs, time the observation render into each, let a candidate replace the slowest ring
         member where it is faster by more than ``min_gain`` (3 %: less is timing noise) and give the rest back.  Values are unaffected; ``self.obs_audition`` records what was measured.
@@ -512,9 +514,62 @@ class TimeSeriesEnv:
         # rebuilt for the new N with every account in its initial state (the recipe's other assignments then match)
         if self.world_size != 1:
             raise ValueError("resizing a sharded env (world_size > 1) is not supported: construct it with num_envs=")
-        self._release_native()
-        self._eval_env = idx.numel() - 1 if not self.evaluate else -1
-        self._allocate_state(idx.clone(), idx.numel(), 0, self.obs_buffers)
+        self._resize(idx.clone())
+
+    # everything _allocate_state (re)binds: what a failed resize puts back
+    _STATE_ATTRS = ("_env_indices", "_num_envs", "global_num_envs", "env_offset", "_spot0", "_cash", "_long", "_short", "_margin",
+                    "_terminated", "_returns", "_counters", "_handle", "_handle_v", "obs_buffers", "_obs_ring", "_obs_next", "_step_fn",
+                    "shares_promoted", "_flag", "_flag_seq", "_flag_word", "flag_timeout_s", "_generation", "_binding_epoch",
+                    "_last_descriptors", "_stepped", "_eval_env", "_mirrors", "_terminated_view_out")
+
+    def _resize(self, idx: torch.Tensor) -> None:
+        """Rebuild state + native env for another env count WITHOUT losing the env when that fails (out of memory while scaling
+        up, a refused fe_env_create): the new state is built beside the old one and swapped in only once it is complete; the old
+        native objects are released after that.  If memory is short the old OBSERVATION RING (output buffers, not state) is
+        given up first and the build retried; a failure after that restores the old state with a fresh ring.  User-set
+        ``flag_timeout_s`` and the device redraw counter carry over; an auditioned ring does not (the storage is new:
+        ``audition_ring`` again if wanted)."""
+        old = {k: self.__dict__[k] for k in self._STATE_ATTRS if k in self.__dict__}
+        if self._dev.type == "cuda":
+            torch.cuda.synchronize(self._dev)  # the last launch may still write the old state / flag
+        redraw_counter = int(self._counters[1].item())
+
+        def attempt():
+            self._handle = self._flag = None  # (nothing below may release the OLD native objects)
+            self._eval_env = idx.numel() - 1 if not self.evaluate else -1
+            try:
+                self._allocate_state(idx, idx.numel(), 0, old["obs_buffers"])
+            except BaseException:
+                h, f = self.__dict__.get("_handle"), self.__dict__.get("_flag")  # what the failed build got as far as creating
+                if f is not None:
+                    self._lib.fe_host_flag_destroy(f)
+                if h is not None:
+                    self._lib.fe_env_destroy(h)
+                self.__dict__.update(old)
+                raise
+
+        try:
+            attempt()
+        except torch.cuda.OutOfMemoryError:
+            ring_shape = [(tuple(t.shape), t.dtype) for t in old["_obs_ring"]]
+            old["_obs_ring"] = self._obs_ring = []
+            torch.cuda.empty_cache()
+            try:
+                attempt()
+            except BaseException:
+                # the env as it was, with a fresh ring (holders of the old buffers' pointers are told: new binding epoch)
+                self._obs_ring = [torch.empty(sh, dtype=dt, device=self._dev) for sh, dt in ring_shape]
+                self._obs_next = 0
+                self._binding_epoch += 1
+                raise
+        # the new env is complete: now the old native objects can go
+        if old.get("_flag") is not None:
+            self._lib.fe_host_flag_destroy(old["_flag"])
+        if old.get("_handle") is not None:
+            self._lib.fe_env_destroy(old["_handle"])
+        self.flag_timeout_s = old["flag_timeout_s"]
+        if not self.evaluate and self.redraw == "device":
+            self._counters[1] = redraw_counter  # the Philox stream goes on where it was
 
     @property
     def cash(self) -> torch.Tensor:
@@ -539,24 +594,50 @@ class TimeSeriesEnv:
         """(N, A) float32 share counts; once a float64-action step has run (``shares_promoted``) a float64 COPY of them, as
         the reference's tensor is float64 from then on (TSE:361; it rebinds the attribute every step, so no caller can rely
         on aliasing it).  Write through assignment (``env.long_shares = t``), not into the returned copy."""
-        return self._long.double() if self.shares_promoted else self._long
+        return self._promoted_mirror("_long") if self.shares_promoted else self._long
 
     @long_shares.setter
     def long_shares(self, value) -> None:
+        self._mirrors.pop("_long", None)
         self._assign("long_shares", self._long, value)
 
     @property
     def short_shares(self) -> torch.Tensor:
         """See ``long_shares`` (TSE:375)."""
-        return self._short.double() if self.shares_promoted else self._short
+        return self._promoted_mirror("_short") if self.shares_promoted else self._short
 
     @short_shares.setter
     def short_shares(self, value) -> None:
+        self._mirrors.pop("_short", None)
         self._assign("short_shares", self._short, value)
+
+    def _promoted_mirror(self, name: str) -> torch.Tensor:
+        """The float64 tensor a promoted env hands out for ``long_shares`` / ``short_shares``: ONE tensor per attribute until the
+        next launch, and whatever the caller wrote into it in place (``env.long_shares[mask] = 0``, ``.zero_()``: what the
+        reference's callers do to its attribute) is copied back into the bound f32 storage before that launch
+        (``_sync_public_views``) -- share counts are small integers, the cast is exact."""
+        m = self._mirrors.get(name)
+        if m is None:
+            m = self._mirrors[name] = getattr(self, name).double()
+        return m
+
+    def _sync_public_views(self) -> None:
+        """Before anything reads the bound state on the device: in-place edits made through handed-out VIEWS that are not the
+        bound storage itself -- the promoted f64 share mirrors, the bool view of the termination flags (whose count the
+        evaluate-mode step compares with num_envs, TSE:531) -- reach the kernel.  Costs nothing unless such a view was handed
+        out since the last launch."""
+        if self._mirrors:
+            for name, m in self._mirrors.items():
+                getattr(self, name).copy_(m)
+            self._mirrors.clear()
+        if self._terminated_view_out:
+            self._counters[0] = self._terminated.sum()
+            self._terminated_view_out = False
 
     @property
     def terminated_episodes(self) -> torch.Tensor:
-        """(N,) bool view of the kernel's u8 flags (TSE:272-274)."""
+        """(N,) bool view of the kernel's u8 flags (TSE:272-274); in-place writes into it are counted before the next step."""
+        self._terminated_view_out = True
         return self._terminated.view(torch.bool)
 
     @terminated_episodes.setter
@@ -624,6 +705,8 @@ class TimeSeriesEnv:
 
     def reset(self) -> torch.Tensor:
         """Render the observation of the current state (TSE:423-435; it resets nothing)."""
+        if self._mirrors or self._terminated_view_out:
+            self._sync_public_views()
         obs = self._next_obs()
         _lib.check(self._lib.fe_env_reset_obs(self._handle, obs.data_ptr(), self._stream()))
         self._last_descriptors, self._stepped = None, False  # the caller now looks at the current state again
@@ -707,6 +790,8 @@ class TimeSeriesEnv:
         ``actions_out`` (N, A) f32 receives a copy of the actions -- ``agent.store``'s action field written by the kernel
         that reads the actions anyway, so the policy's output can stay where the policy wrote it."""
         N, A = self._num_envs, self.num_assets
+        if self._mirrors or self._terminated_view_out:
+            self._sync_public_views()
         act_f64 = False
         if actions.dtype is not torch.float32:
             if self.cast_actions:

@@ -101,6 +101,7 @@ class GraphedRollout:
         if env._binding_epoch != self._captured_epoch:
             raise RuntimeError("the env was resized (env_indices assigned with another length) after this graph was captured: its "
                                "launches point at the old state -- capture a new GraphedRollout")
+        env._sync_public_views()  # in-place edits through handed-out views (promoted share mirrors, terminated_episodes) reach the replay
         self.graph.replay()
         # the replay advanced the env K steps without passing through env.step(): fused rollout objects sharing this env
         # must see their observation descriptors as stale (_FusedEvaluation._begin_run).  Callers that step through
@@ -249,6 +250,7 @@ class _FusedEvaluation:
         another rollout object's ``run`` -- the two no longer belong together and the policy would act on a stale
         observation while the accounting uses the current state: refuse instead of running on silently."""
         self._check_epoch()
+        self.env._sync_public_views()
         if getattr(self.env, "shares_promoted", False):
             raise RuntimeError("this env was stepped with float64 actions: the reference computes its commissions in f64 from then on "
                                "(fe_env_step_promoted); the fused rollouts run the f32 arithmetic only")

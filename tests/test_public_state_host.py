@@ -25,7 +25,11 @@ def host_env(N=6, A=1, W=4, D=3, L=20, evaluate=True):
     env._returns = torch.zeros((N,))
     env._counters = torch.zeros((2,), dtype=torch.int64)
     env.shares_promoted = False
-    env.obs_buffers = 0
+    env._mirrors, env._terminated_view_out = {}, False
+    env.obs_buffers, env._obs_ring, env._obs_next = 0, [], 0
+    env.flag_timeout_s, env._flag, env._flag_seq = 60.0, None, 0
+    env._binding_epoch, env._generation, env._eval_env = 0, 1, (-1 if evaluate else N - 1)
+    env.redraw = "torch"
     env._handle = env._lib = None  # (__del__ / _release_native: nothing to destroy)
     return env
 
@@ -100,16 +104,47 @@ def test_setters_refuse_what_does_not_fit():
         sharded.env_indices = torch.arange(8) % 3
 
 
+def _fake_allocate(log, fail_at=None):
+    def allocate(self, idx, total, lo, obs_buffers):
+        log.append(("allocate", idx.tolist(), total, lo, obs_buffers))
+        self._env_indices, self._num_envs = idx, idx.numel()      # half-way through the real _allocate_state ...
+        self._cash = torch.full((idx.numel(), 1), 1000.0)
+        self.flag_timeout_s = 60.0                                # ... which also resets the knobs
+        if fail_at is not None and len(log) >= fail_at:
+            raise RuntimeError("fe_env_create failed: out of device memory")
+        self._counters = torch.zeros((2,), dtype=torch.int64)
+        self._binding_epoch += 1
+    return allocate
+
+
 def test_another_length_rebuilds_the_env(monkeypatch):
-    """Assigning env_indices of another length (SURVEY Appendix B's first statement) releases the native env and allocates
-    the state for the new N; the evaluation env of a training-mode env is the LAST env of the new batch (TSE:253-257, 510)."""
+    """Assigning env_indices of another length (SURVEY Appendix B's first statement) allocates the state for the new N; the
+    evaluation env of a training-mode env is the LAST env of the new batch (TSE:253-257, 510); user-set knobs survive."""
     env = host_env(evaluate=False)
+    env.flag_timeout_s = 5.0
     calls = []
-    monkeypatch.setattr(TimeSeriesEnv, "_release_native", lambda self: calls.append("release"))
-    monkeypatch.setattr(TimeSeriesEnv, "_allocate_state",
-                        lambda self, idx, total, lo, obs_buffers: calls.append(("allocate", idx.tolist(), total, lo, obs_buffers)))
+    monkeypatch.setattr(TimeSeriesEnv, "_allocate_state", _fake_allocate(calls))
     env.env_indices = torch.arange(8) % 3
-    assert calls == ["release", ("allocate", [0, 1, 2, 0, 1, 2, 0, 1], 8, 0, 0)] and env._eval_env == 7
+    assert calls == [("allocate", [0, 1, 2, 0, 1, 2, 0, 1], 8, 0, 0)] and env._eval_env == 7 and env.num_envs == 8
+    assert env.flag_timeout_s == 5.0 and env._binding_epoch == 1
+
+
+def test_a_failed_resize_leaves_the_env_as_it_was(monkeypatch):
+    """the resize used to destroy the native env BEFORE building the new one -- a failure (out of memory while
+    scaling up) left an object without a handle and with half-updated sizes.  Now the old state comes back whole."""
+    env = host_env(evaluate=False)
+    env._cash[:] = 123.0
+    env._handle, env.flag_timeout_s = "old-handle", 5.0
+    before = {k: env.__dict__[k] for k in TimeSeriesEnv._STATE_ATTRS if k in env.__dict__}
+    calls = []
+    monkeypatch.setattr(TimeSeriesEnv, "_allocate_state", _fake_allocate(calls, fail_at=1))
+    with pytest.raises(RuntimeError, match="out of device memory"):
+        env.env_indices = torch.arange(8) % 3
+    assert len(calls) == 1
+    for k, v in before.items():
+        assert env.__dict__[k] is v or env.__dict__[k] == v, k
+    assert env.num_envs == 6 and env._handle == "old-handle" and float(env.cash.sum()) == 6 * 123.0 and env._eval_env == 5
+    env._handle = None  # (nothing native behind the test's stand-in)
 
 
 def test_promoted_env_shows_float64_share_tensors():
@@ -121,3 +156,26 @@ def test_promoted_env_shows_float64_share_tensors():
     assert float(env.long_shares.sum()) == 18.0 and env._long.dtype is torch.float32
     env.long_shares = torch.ones((6, 1), dtype=torch.float64)   # written through assignment
     assert float(env._long.sum()) == 6.0
+    # in-place edits of the handed-out f64 tensor (what the reference's callers do to its attribute) used to be
+    # dropped silently.  The getter hands out ONE mirror per attribute until the next launch, and the launch path copies it back.
+    m = env.long_shares
+    assert m is env.long_shares and m.dtype is torch.float64 and float(m.sum()) == 6.0
+    m[:2] = 4.0
+    env.short_shares.fill_(2.0)
+    env._sync_public_views()                         # what step() / reset() / a graph replay do first
+    assert env._long[:, 0].tolist() == [4.0, 4.0, 1.0, 1.0, 1.0, 1.0] and float(env._short.sum()) == 12.0 and not env._mirrors
+    assert env.long_shares is not m and float(env.long_shares.sum()) == 12.0   # a fresh copy of the bound storage after the launch
+    env.long_shares.zero_()
+    env.long_shares = torch.full((6, 1), 5.0)        # an assignment after an in-place edit wins (the mirror is dropped)
+    env._sync_public_views()
+    assert float(env._long.sum()) == 30.0
+
+
+def test_in_place_writes_through_the_terminated_view_are_counted_before_the_next_step():
+    env = host_env()
+    env.terminated_episodes = torch.tensor([1, 0, 1, 1, 0, 0])
+    assert int(env._counters[0]) == 3
+    env.terminated_episodes[1] = True                # the bool view writes the kernel's flags; the count is stale until ...
+    env.terminated_episodes[4:] = True
+    env._sync_public_views()                         # ... the launch path recounts
+    assert int(env._counters[0]) == 6 and not env._terminated_view_out

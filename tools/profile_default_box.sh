@@ -11,8 +11,11 @@ stats = list(csv.DictReader(open(glob.glob(out + "/trace/*/*_kernel_stats.csv")[
 b = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
 lines = [f"# {tag}: `rocprofv3 --kernel-trace --stats -- python3 bench.py --gpus 1 --steps 20 --warmup 5 --no-pmc`", ""]
 lines.append(f"bench.py line of the same run: value {b['value']:.4g} env-steps/s, ms_per_step {b['ms_per_step']*1e3:.2f} us, kernel_ms {b['roofline']['kernel_ms']*1e3:.2f} us (HIP events), frac {b['roofline']['frac']:.3f}")
+lines.append(f"(the line itself: {len(open(out + '/bench.json').read().strip().splitlines()[-1])} characters)")
 for e in b["extra_configs"]:
     lines.append(f"  extra: {e['workload']}: value {e['value']:.4g}, kernel_ms {e['roofline']['kernel_ms']*1e3:.1f} us, frac {e['roofline']['frac']:.3f}")
+for x in b.get("legs", []):
+    lines.append(f"  leg: {x['leg']}: value {x.get('value')}, ms_per_step {x.get('ms_per_step')}, frac {x.get('frac')}")
 lines += ["", "| kernel | calls | avg us | min us | max us | % of GPU time |", "|---|---|---|---|---|---|"]
 for r in sorted(stats, key=lambda r: -float(r["TotalDurationNs"]))[:8]:
     lines.append(f"| `{r['Name'].replace('(anonymous namespace)::', '')[:70]}` | {r['Calls']} | {float(r['AverageNs'])/1e3:.2f} | {float(r['MinNs'])/1e3:.2f} | {float(r['MaxNs'])/1e3:.2f} | {r['Percentage']} |")

@@ -79,7 +79,12 @@ def main():
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in stats:
             w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"], r["MaxNs"], r["StdDev"]])
-    bench = json.loads(open(os.path.join(src, "bench_trace.json")).read().strip().splitlines()[-1])
+    # the run's full record (bench.py --detail; the stdout line is a summary of it since round 6)
+    full = json.load(open(os.path.join(src, "bench_detail.json")))
+    head = full["headline"]
+    bench = {"roofline": head["roofline"], "dtype": full["dtype"], "steps": head["steps"], "warmup": head["warmup"], "value": head["value"],
+             "ms_per_step": head["ms_per_step"], "repeats": head["repeats"],
+             "config": {"workload": head["workload"], "eval_redraw": full["eval_redraw"], "launch": head["launch"]}}
     r = bench["roofline"]
     headline_kernel = r.get("kernel", "")
     by_form = dispatches(trace)
@@ -187,7 +192,7 @@ def main():
             f.write("The LOOP average is above the TRAINS average although almost all of its launches are queued back to back: in time order "
                     "(quarters above) the same kernel runs at the TRAINS figure at first, 10 - 20 % longer from ~1 ms after the GPU left its idle state, "
                     "and comes back over ~10 ms -- a clock / power transient after the idle period of env construction, not a property of the "
-                    "launch path (tools/slot_rotation.py: moving trajectory slots cost +0.2 us).  A run with more blocks (the default command: "
+                    "launch path (moving trajectory slots cost +0.2 us, NOTES.md round 4).  A run with more blocks (the default command: "
                     "median of up to 40) sits in the settled regime.\n\n")
         if tight:
             dev = (r["kernel_ms"] * 1e6 - tight["avg_ns"]) / tight["avg_ns"] * 100
