@@ -585,6 +585,11 @@ __device__ __forceinline__ void env_kernel_body(const Params &p) {
     }
 }
 
+// KERNARG LAYOUT CONTRACT (Cold<true> above): `Params` is the FIRST and ONLY explicit argument of both wrappers, so the kernarg
+// segment pointer IS a `const Params *`.  A kernel with a leading argument must not instantiate FORM 3 with SINGLE (or must pass
+// the block's offset to Cold).  tests/test_resource_usage.py reads the code object's metadata and fails if this stops being true.
+static_assert(std::is_trivially_copyable<Params>::value && sizeof(Params) % 8 == 0,
+              "Params is passed by value in the kernarg segment and re-read from there (Cold<true>)");
 template <typename OT, int VEC, bool SINGLE, bool RESET_ONLY, int FORM>
 __global__ __launch_bounds__(kBlock, (kEnvKernelWaves<OT, VEC, SINGLE, RESET_ONLY>)) void fe_env_kernel(const Params p) {
     env_kernel_body<OT, VEC, SINGLE, RESET_ONLY, FORM, false>(p);

@@ -80,3 +80,33 @@ def test_committed_table_matches_this_build(table):
             assert line is not None, f"{r['name']} missing from {path}: regenerate it"
             cols = line[58:].split()
             assert int(cols[3]) == r["scratch"], (r["name"], line)
+
+
+def test_params_is_the_first_kernel_argument_wherever_cold_parameters_are_read_from_the_kernarg_segment():
+    """fe_step_kernel.h `Cold<true>` reinterprets the kernarg segment pointer as `Params *` (FORM 3 of the single-asset step kernels:
+    mode-specific parameters are s_loaded at their use instead of living in spilled SGPRs).  That is only right while `Params` is the
+    FIRST by-value argument, at offset 0, of every kernel that reaches account_core / the evaluate tail -- nothing in the language
+    enforces it.  The code object's own metadata does: every kernel that takes Params takes it first, and the step
+    kernels take nothing else."""
+    import resource_usage
+
+    from finenvs_amd.csrc import build as hip_build
+
+    if not os.path.exists(hip_build.HIPCC):
+        pytest.skip("hipcc not available")
+    args = resource_usage.kernel_arguments()
+    step = {n: a for n, a in args.items() if n.startswith(("fe_env_kernel<", "fe_env_promoted_kernel<"))}
+    assert len(step) == 64
+    sizes = {a[0][1] for a in step.values()}
+    assert len(sizes) == 1, sizes
+    params_size = sizes.pop()
+    for name, a in step.items():
+        assert a[0] == (0, params_size, "by_value"), (name, a[0])
+        assert all(kind.startswith("hidden_") for _, _, kind in a[1:]), (name, a[1:])  # Params is the ONLY explicit argument
+    # the instantiations that actually launder the pointer today
+    assert "fe_env_kernel<double, 2, true, false, 3>" in step and "fe_env_promoted_kernel<double, 2, true, 3>" in step
+    # every other kernel that takes the parameter block takes it first as well (a fused rollout reusing account_core<., 3> would
+    # read the right bytes)
+    for name, a in args.items():
+        if any(size == params_size and kind == "by_value" for _, size, kind in a):
+            assert a[0] == (0, params_size, "by_value"), (name, a[:2])

@@ -50,6 +50,33 @@ def kernel_table(defines=()):
     return rows
 
 
+def kernel_arguments():
+    """{demangled kernel name: [(offset, size, value_kind), ...]} from the code object's own metadata (device-only compile,
+    clang-offload-bundler --unbundle, llvm-readelf --notes): what the hardware's kernarg segment of each kernel looks like."""
+    import yaml
+
+    from finenvs_amd.csrc import build as B
+
+    llvm = os.path.join(os.path.dirname(B.HIPCC), "..", "lib", "llvm", "bin")
+    with tempfile.TemporaryDirectory(prefix="fe_ka_") as tmp:
+        co, elf = os.path.join(tmp, "dev.co"), os.path.join(tmp, "dev.elf")
+        flags = [f for f in B.FLAGS if f not in ("-shared", "-fPIC")]
+        subprocess.run([B.HIPCC] + flags + ["--offload-device-only", "-c", os.path.join(B.HERE, "fe_env.hip"), "-o", co],
+                       capture_output=True, text=True, check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", f"--input={co}",
+                        "--targets=hip-amdgcn-amd-amdhsa--gfx950", f"--output={elf}"], capture_output=True, text=True, check=True)
+        notes = subprocess.run([os.path.join(llvm, "llvm-readelf"), "--notes", elf], capture_output=True, text=True, check=True).stdout
+    doc = notes[notes.index("---"):]
+    doc = doc[:doc.index("\n...") + 1] if "\n..." in doc else doc
+    meta = yaml.safe_load(doc)
+    kernels = meta["amdhsa.kernels"]
+    names = demangle([k[".name"] for k in kernels])
+    out = {}
+    for k, name in zip(kernels, names):
+        out[re.sub(r"^void ", "", re.sub(r"\(.*\)$", "", name))] = [(a[".offset"], a[".size"], a[".value_kind"]) for a in k.get(".args", [])]
+    return out
+
+
 def format_table(rows):
     lines = [f"{'kernel':58s} {'vgpr':>4} {'agpr':>4} {'sgpr':>4} {'scratch B/lane':>14} {'vgpr spill':>10} {'sgpr spill':>10} {'waves/SIMD':>10} {'LDS static':>10}"]
     for r in sorted(rows, key=lambda r: r["name"]):
