@@ -14,7 +14,7 @@ back-to-back C-ABI launches (fe_env_step_traj, lean form, redraw='device'), HIP 
   window      an env of the same bytes per launch with W = 128 (131 072 envs x 30 x W128 = 20.1 GB) on the SAME buffers as (i) / (iii),
               and the config-4 env itself on the whole slab
 
-Writes a table to stdout (copy it to profiles/r06_microbench/slab_ring.txt)."""
+Writes a table to stdout (copy it to profiles/r06_microbench/config3_launch_size.md)."""
 import os
 import statistics
 import sys
