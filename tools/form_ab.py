@@ -1,7 +1,12 @@
-"""GPU box: the four FORMs of the step kernel (0 lean, 1 full, 2 lean + host flag, 3 full + host flag) on ONE env and ONE
+"""GPU box: the FORMs of the single-asset f64 step kernel (0 lean, 1 full, 2 lean + host flag, 3 full + host flag) on ONE env and ONE
 observation ring, trains of back-to-back C-ABI launches, interleaved rounds (config 2: 64k envs x W64, f64 observations).
 
     python tools/form_ab.py [rounds]
+
+Every arm is labelled by the instantiation launch_env (csrc/fe_env.hip) really dispatches it to: the FULL forms are reached only
+with trajectory DESCRIPTORS (or statistics / evaluate mode) -- since round 5 the action copy alone stays on the lean forms, so
+"step_traj with the action copy" is a lean-form arm of its own (the round-5 version of this tool still printed
+those arms as FORM 1 / FORM 3).
 """
 import os, statistics, sys
 import torch
@@ -33,16 +38,33 @@ dev_flag = torch.zeros((1,), dtype=torch.int64, device="cuda:0")
 dev_flag_p = ctypes.c_void_p(dev_flag.data_ptr())
 
 
-def launch(form, i):
-    if form == 0:
-        return L.fe_env_step(h, ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr(), st)
-    if form == 1:
-        return L.fe_env_step_traj(h, ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr(), acopy.data_ptr(), None, None, st)
+src = torch.empty((N,), dtype=torch.int64, device="cuda:0")       # trajectory descriptors: what selects the FULL forms
+pos = torch.empty((N, A), dtype=torch.float64, device="cuda:0")
+
+# arm -> (label, entry point, action copy, descriptors, host flag: None / "host" / "device")
+ARM_SPEC = {
+    "F0":        ("FORM 0  lean                      fe_env_step", "step", False, False, None),
+    "F0+acopy":  ("FORM 0  lean + action copy        fe_env_step_traj(actions_out)", "traj", True, False, None),
+    "F1":        ("FORM 1  full (descriptors)        fe_env_step_traj(actions_out, obs_src, obs_pos)", "traj", True, True, None),
+    "F2":        ("FORM 2  lean + host flag          fe_env_step_notify", "step", False, False, "host"),
+    "F2+acopy":  ("FORM 2  lean + flag + action copy fe_env_step_traj_notify(actions_out)   <- bench.py's headline", "traj", True, False, "host"),
+    "F3":        ("FORM 3  full + host flag          fe_env_step_traj_notify(actions_out, obs_src, obs_pos)", "traj", True, True, "host"),
+    "F2dev":     ("FORM 2  lean, flag word in DEVICE memory", "step", False, False, "device"),
+    "F3dev":     ("FORM 3  full, flag word in DEVICE memory", "traj", True, True, "device"),
+}
+
+
+def launch(arm, i):
+    _, entry, ac, desc, flagkind = ARM_SPEC[arm]
+    a, o, r, d = ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr()
+    outs = (acopy.data_ptr() if ac else None, src.data_ptr() if desc else None, pos.data_ptr() if desc else None)
+    if flagkind is None:
+        return L.fe_env_step(h, a, o, r, d, st) if entry == "step" else L.fe_env_step_traj(h, a, o, r, d, *outs, st)
     seq[0] += 1
-    flag = env._flag if form < 4 else dev_flag_p
-    if form in (2, 4):
-        return L.fe_env_step_notify(h, ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr(), flag, seq[0], st)
-    return L.fe_env_step_traj_notify(h, ap[i % 8], obs[i % 2], rew.data_ptr(), done.data_ptr(), acopy.data_ptr(), None, None, flag, seq[0], st)
+    flag = env._flag if flagkind == "host" else dev_flag_p
+    if entry == "step":
+        return L.fe_env_step_notify(h, a, o, r, d, flag, seq[0], st)
+    return L.fe_env_step_traj_notify(h, a, o, r, d, *outs, flag, seq[0], st)
 
 
 def train(form, k=400):
@@ -57,7 +79,7 @@ def train(form, k=400):
     return e0.elapsed_time(e1) / k * 1e3
 
 
-ARMS = (0, 1, 2, 3, 4, 5)
+ARMS = tuple(ARM_SPEC)
 for f in ARMS:
     train(f, 800)  # settle
 res = {f: [] for f in ARMS}
@@ -66,4 +88,4 @@ for r in range(rounds):
         res[f].append(train(f))
 for f in ARMS:
     v = res[f]
-    print(f"{'FORM %d' % f if f < 4 else 'FORM %d, flag in device memory' % (f - 2)}: median {statistics.median(v):.2f} us  min {min(v):.2f}  max {max(v):.2f}   {['%.2f' % x for x in v]}")
+    print(f"{ARM_SPEC[f][0]}: median {statistics.median(v):.2f} us  min {min(v):.2f}  max {max(v):.2f}   {['%.2f' % x for x in v]}")

@@ -101,7 +101,7 @@ def main():
     print(f"\n# 131 072 envs per launch, automatic geometry: {info0}")
     print("| tile_envs | grid | ms per launch | frac of 8 TB/s |\n|---|---|---|---|")
     B = (40 * W * A + 84 * A + 36) * (FULL // 8)
-    for tile, grid in ((0, 0), (0, 1280), (0, 1024), (0, 768), (0, 512), (0, 256), (4, 0), (2, 0), (1, 0), (4, 1024), (2, 1024), (2, 2048), (1, 2048)):
+    for tile, grid in ((0, 0), (0, 1024), (0, 512), (0, 256), (4, 0), (1, 0), (2, 2048), (8, 3072), (8, 4096), (8, 8192), (8, 16384), (4, 32768), (2, 65536), (1, 131072), (4, 8192), (2, 8192), (0, 0)):
         try:
             info = env.set_launch(tile_envs=tile, grid=grid)
         except Exception as exc:  # noqa: BLE001
@@ -169,6 +169,45 @@ def main():
         cover_fill(1)
         ms = statistics.median(cover_fill(covers) for _ in range(3))
         print(f"| {step_w * 8 / 1e9:.2f} GB per launch | {k} | {ms:.2f} | {nw * 8 / ms / 1e9:.2f} |", flush=True)
+    # ---- where in the slab?  The same 16 parts, each timed on its own: this kernel (65 536 envs per launch, 6 launches back to back
+    # into ONE part) and torch's fill of the same bytes.  If both see the same slow / fast parts it is the memory; if only this
+    # kernel does, it is the kernel's access pattern on that memory.
+    print("\n| part of the slab (1/16 = 10 GB each) | this kernel: TB/s on B_hbm | torch fill: TB/s |\n|---|---|---|")
+    k = 16
+    N = FULL // k
+    env, rew, done, act = envs[k]
+    fn, h, st = env._lib.fe_env_step_traj, env._handle_v, torch.cuda.current_stream().cuda_stream
+    Bp = (40 * W * A + 84 * A + 36) * N
+    step_w = nw // k
+    for part in range(k):
+        def mine(reps):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            rc = 0
+            for i in range(reps):
+                rc = fn(h, acts_full[i % 2].data_ptr() + part * N * A * 4, base + part * N * per_env, rew.data_ptr(), done.data_ptr(), act.data_ptr(),
+                        None, None, st) or rc
+            e1.record()
+            torch.cuda.synchronize()
+            if rc:
+                _fl.check(rc)
+            return e0.elapsed_time(e1) / reps
+
+        def fill(reps):
+            v = words[part * step_w:(part + 1) * step_w]
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(reps):
+                v.fill_(7)
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) / reps
+
+        mine(2)
+        m = statistics.median(mine(6) for _ in range(3))
+        fill(2)
+        f = statistics.median(fill(6) for _ in range(3))
+        print(f"| {part} | {Bp / m / 1e9:.2f} | {step_w * 8 / f / 1e9:.2f} |", flush=True)
     print(f"\n# total {time.perf_counter() - t00:.0f} s")
 
 
