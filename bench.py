@@ -1011,8 +1011,13 @@ def render_line(detail: dict) -> str:
     return s[:LINE_CAP]  # unreachable with the sections above gone (the core is ~2.5 KB)
 
 
+_EMIT_DETAIL = [True]  # main() switches it off on ranks other than 0 (one copy of every record, not one per rank)
+
+
 def emit_detail(tag: str, obj) -> None:
     """Full records go to stderr, one JSON line each (the driver keeps stderr beside stdout); never to stdout."""
+    if not _EMIT_DETAIL[0]:
+        return
     try:
         print(f"[bench-detail] {json.dumps({tag: strict(obj)}, allow_nan=False)}", file=sys.stderr, flush=True)
     except Exception as exc:  # noqa: BLE001
@@ -1136,6 +1141,7 @@ def main():
         print("bench.py --graph: hipGraph capture cannot contain the per-step host read of redraw='torch' -> redraw='device'", file=sys.stderr)
         args.redraw = "device"
     D = Dist(args)
+    _EMIT_DETAIL[0] = D.rank == 0
     t_start = time.perf_counter()
 
     def note(msg):
