@@ -726,6 +726,29 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
     kern_ms = statistics.median(kern)
     form = train[0].form
 
+    # The practical store ceiling beside the roofline: torch's fill kernel (one aligned 4 KiB unit per workgroup, one store per
+    # lane: the fastest way of writing HBM found on this part) over the SAME observation ring, in the same
+    # train protocol as `kernel_ms` (back-to-back launches, alternating ring members, one HIP-event pair per train).  Pure stores:
+    # it reads nothing and computes nothing, so it bounds what any kernel that has to produce these bytes can reach here.
+    fill_ms = None
+    try:
+        ring = list(env._obs_ring)
+        if ring:
+            kf = max(4, min(k2, 60))
+            fills = []
+            for rep in range(4):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for i in range(kf):
+                    ring[i % len(ring)].fill_(0.0)
+                e1.record()
+                torch.cuda.synchronize()
+                if rep:
+                    fills.append(e0.elapsed_time(e1) / kf)
+            fill_ms = statistics.median(fills)
+    except Exception as exc:  # noqa: BLE001
+        print(f"bench.py: store-ceiling fill skipped ({type(exc).__name__}: {exc})", file=sys.stderr)
+
     Bh = hbm_bytes(W, A, obs_elem)
     Bs = survey_bytes(W, A) - (4 * W * 5 * A if args.obs_f32 else 0)
     l2_read = (16 if args.obs_f32 else 32) * W * A  # window re-read per env-step, served by L2 / Infinity Cache
@@ -774,6 +797,10 @@ def run_workload(config: int, args, D: Dist, steps: int, warmup: int, repeats: i
             "survey_8d_bytes_per_env_step": Bs,
             # whole-job check: HBM bytes / wall ms_per_step (must stay below the peak as well)
             "achieved_wall": Bh * N / (block / steps) / 1e9,
+            # torch's fill over the same ring, same train protocol: observation bytes / launch interval, and this kernel's
+            # observation bytes alone over `kernel_ms` for the like-for-like comparison
+            "fill_ms": fill_ms, "fill_GBps": (obs_bytes / (fill_ms * 1e-3) / 1e9) if fill_ms else None,
+            "obs_write_GBps": obs_bytes / (kern_ms * 1e-3) / 1e9,
         },
     }
     if D.multi:
@@ -875,6 +902,9 @@ def compact_roofline(r: dict, full: bool) -> dict:
         out["traffic_live_error"] = _short(r["traffic_live_error"], 140)
     if r.get("traffic") and r.get("hbm_bytes_per_env_step"):
         out["traffic_over_algorithmic"] = _sig(r["traffic"] / (r["hbm_bytes_per_env_step"] * r["units_per_launch"]), 4)
+    if r.get("fill_GBps"):  # the practical store ceiling on the same ring (torch's fill, same train protocol) and this kernel's share of it
+        out["fill_GBps"] = _sig(r["fill_GBps"], 5)
+        out["obs_write_over_fill"] = _sig(r["obs_write_GBps"] / r["fill_GBps"], 4)
     if full:
         out.update(bytes_model=r.get("bytes_model"), survey_8d_bytes_per_env_step=r.get("survey_8d_bytes_per_env_step"),
                    frac_on_survey_8d_bytes=_sig(r.get("frac_on_survey_8d_bytes"), 4), achieved_wall=_sig(r.get("achieved_wall")),
