@@ -328,3 +328,83 @@ def test_refused_float64_step_does_not_promote(fe, fo):
     assert not env.shares_promoted and env.long_shares.dtype is torch.float32
     env.step(a64)
     assert env.shares_promoted and env.long_shares.dtype is torch.float64
+
+
+def test_in_place_edits_of_a_promoted_envs_share_tensors_reach_the_kernel(fe, fo):
+    """on a promoted env `long_shares` / `short_shares` used to hand out a detached float64 copy, so the in-place
+    edits the reference's callers make (`env.long_shares[mask] = 0`, `.zero_()`) were dropped silently.  The getter now hands out
+    one float64 mirror per attribute until the next launch and the launch path copies it back: the in-place edit and the
+    assignment give the same steps, bit for bit, and both differ from an env that was not edited."""
+    from finenvs_amd.data import synthetic
+
+    W, N = 8, 200
+    prices, day_id, _ = synthetic.synthetic_series(6, 1, 40, 11)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    mk = lambda: fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, starting_balance=900)  # noqa: E731
+    a_env, b_env, c_env = mk(), mk(), mk()
+    g = torch.Generator().manual_seed(5)
+    for t in range(6):  # build positions; the first step's float64 actions promote all three
+        a = (torch.rand((N, 1), generator=g, dtype=torch.float64) * 2 - 1).cuda()
+        for e in (a_env, b_env, c_env):
+            e.step(a if t == 0 else a.float())
+    assert a_env.shares_promoted and float(a_env.long_shares.sum() + a_env.short_shares.sum()) > 0
+    mask = torch.arange(N, device="cuda") % 3 == 0
+    la = a_env.long_shares
+    assert la.dtype is torch.float64 and la is a_env.long_shares     # one mirror until the next launch
+    la[mask] = 0.0                                                   # the reference caller's idiom
+    a_env.short_shares.mul_(0.0)
+    lb = b_env.long_shares.clone()
+    lb[mask] = 0.0
+    b_env.long_shares = lb                                           # the documented way: assignment
+    b_env.short_shares = torch.zeros((N, 1))
+    differs = False
+    for t in range(10):
+        a = (torch.rand((N, 1), generator=g) * 2 - 1).cuda()
+        oa, ra, da, _ = a_env.step(a)
+        ob, rb, db, _ = b_env.step(a)
+        oc, rc_, dc, _ = c_env.step(a)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(da, db), f"step {t}"
+        for name in ("cash", "margin", "long_shares", "short_shares"):
+            assert torch.equal(getattr(a_env, name), getattr(b_env, name)), name
+        differs = differs or not torch.equal(ra, rc_)
+    assert differs, "zeroing a third of the long positions must change some reward"
+    assert a_env.long_shares is not la                               # a fresh mirror after the launches
+    # the bool view of the termination flags: in-place writes are counted before the next evaluate-mode step (TSE:531)
+    a_env.reset_evaluation_metrics()
+    a_env.terminated_episodes[:] = True
+    _, _, _, info = a_env.step(torch.zeros((N, 1), device="cuda"))
+    assert "returns" in info and info["returns"].shape == (N,)
+
+
+def test_a_resize_that_fails_on_the_device_leaves_a_working_env(fe, fo, monkeypatch):
+    """the resize destroyed the native env before building the new one.  With fe_env_create failing (stand-in for
+    an out-of-memory while scaling up, Appendix B's recipe) the env keeps its handle, its sizes, its state and its user-set knobs,
+    and goes on stepping exactly like a twin that was never asked to resize."""
+    from finenvs_amd import _lib
+    from finenvs_amd.data import synthetic
+
+    W, N = 8, 64
+    prices, day_id, _ = synthetic.synthetic_series(5, 1, 40, 3)
+    P, LR, *_ = fo.tables_from_series(prices, day_id, W)
+    D = P.shape[0]
+    env = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_buffers=2)
+    twin = fe.TimeSeriesEnv(tables=(P, LR), num_intervals=W, num_envs=N, evaluate=True, obs_buffers=2)
+    env.flag_timeout_s = 7.0
+    g = torch.Generator().manual_seed(1)
+    for _ in range(5):
+        a = (torch.rand((N, 1), generator=g) * 2 - 1).cuda()
+        env.step(a), twin.step(a)
+    handle, ring = env._handle_v, [t.data_ptr() for t in env._obs_ring]
+    monkeypatch.setattr(env._lib, "fe_env_create", lambda *args: _lib.FE_ERR_ARG)
+    with pytest.raises(Exception):
+        env.env_indices = torch.arange(4 * N) % D
+    monkeypatch.undo()
+    assert env.num_envs == N and env._handle_v == handle and [t.data_ptr() for t in env._obs_ring] == ring and env.flag_timeout_s == 7.0
+    for t in range(5):
+        a = (torch.rand((N, 1), generator=g) * 2 - 1).cuda()
+        o1, r1, d1, _ = env.step(a)
+        o2, r2, d2, _ = twin.step(a)
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2), f"step {t} after the failed resize"
+    env.env_indices = torch.arange(2 * N) % D                        # and a resize that works still works
+    assert env.num_envs == 2 * N and env.flag_timeout_s == 7.0 and env._handle_v != handle
+    env.step(torch.zeros((2 * N, 1), device="cuda"))
