@@ -139,7 +139,7 @@ def pmc_traffic(config: int, f32: bool):
 
 
 _LIVE_PMC_BROKEN = []  # "no profiler can run in this process at all" (already profiled / no rocprofv3): never asked again
-PMC_CHILD_TIMEOUT_S = 150.0  # one counter-pass child (import + tables + a 154 GB first touch + 16 launches under the profiler)
+PMC_CHILD_TIMEOUT_S = 90.0  # one counter-pass child (import + tables + a 154 GB first touch + 16 launches under the profiler)
 _PROFILER_ENV_PREFIXES = ("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_", "ROCTX_")
 
 
@@ -185,6 +185,26 @@ def pmc_child_env(environ=None) -> dict:
         env.pop("LD_PRELOAD", None)
     env["TMPDIR"] = "/tmp"
     return env
+
+
+_CHILD = [None]  # the counter-pass child in flight (a Popen in its own process group), if any
+
+
+def kill_child() -> None:
+    """End the counter-pass child in flight -- the process group this script started, by its id -- and reap it."""
+    import signal
+
+    proc = _CHILD[0]
+    if proc is None or proc.poll() is not None:
+        return
+    try:
+        os.killpg(proc.pid, signal.SIGKILL)  # (start_new_session=True: the group's id is the child's pid)
+    except (ProcessLookupError, PermissionError):
+        pass
+    try:
+        proc.wait(timeout=10)
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def _last_words(path: str, limit: int = 110) -> str:
@@ -234,13 +254,19 @@ def live_pmc_traffic(config: int, f32: bool, redraw: str, no_audition: bool = Fa
             if no_audition:
                 cmd.append("--no-audition")
             errp = os.path.join(out, kind + ".err")
-            try:
-                with open(errp, "w") as ef:
-                    r = subprocess.run(cmd, cwd="/tmp", env=pmc_child_env(), stdout=subprocess.DEVNULL, stderr=ef, timeout=PMC_CHILD_TIMEOUT_S)
-            except subprocess.TimeoutExpired:
-                return None, f"--pmc {kind} child of config {config} not done after {PMC_CHILD_TIMEOUT_S:g} s: {_last_words(errp, 60)}"
-            if r.returncode != 0:
-                return None, f"--pmc {kind} child of config {config} exited {r.returncode}: {_last_words(errp)}"
+            with open(errp, "w") as ef:
+                # its own process group, remembered in _CHILD: a timeout here or the line's watchdog ends exactly this group
+                proc = subprocess.Popen(cmd, cwd="/tmp", env=pmc_child_env(), stdout=subprocess.DEVNULL, stderr=ef, start_new_session=True)
+                _CHILD[0] = proc
+                try:
+                    rc = proc.wait(timeout=PMC_CHILD_TIMEOUT_S)
+                except subprocess.TimeoutExpired:
+                    kill_child()
+                    return None, f"--pmc {kind} child of config {config} not done after {PMC_CHILD_TIMEOUT_S:g} s: {_last_words(errp, 60)}"
+                finally:
+                    _CHILD[0] = None
+            if rc != 0:
+                return None, f"--pmc {kind} child of config {config} exited {rc}: {_last_words(errp)}"
             rows = []
             for f in glob.glob(os.path.join(out, kind, "*", "*_counter_collection.csv")):
                 for row in csv.DictReader(open(f)):
@@ -333,6 +359,10 @@ class Dist:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
             kw = {"timeout": datetime.timedelta(minutes=5)}
+            # ProcessGroupNCCL's heartbeat-monitor thread polls the TCPStore; at teardown the store can go first and the thread's
+            # exception then std::terminate()s the process (seen once in ~10 rehearsals: exit code -6 after all the work was done).
+            # The monitor only serves torch's own hang diagnostics; this script has its watchdog.
+            os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")
             # RCCL's own account of what it chose (algorithm / protocol / channels) goes to a per-process file that rank 0
             # summarises into multi_gpu.rccl (NCCL_DEBUG_FILE keeps it off stdout / stderr); FE_BENCH_RCCL_DEBUG=0 switches it off
             self.rccl_log = None
@@ -1124,6 +1154,7 @@ class LineGuard:
             self.detail.setdefault("unfinished", []).append(self.current[0])
             self.detail["watchdog"] = msg
             self.print_once()
+            kill_child()  # a rocprofv3 counter pass in flight must not outlive this process on the GPU
             if self.rank != 0:
                 time.sleep(4.0)
             os._exit(self.EXIT_CODE)
@@ -1291,11 +1322,23 @@ def main():
 
     guard.current[0] = "teardown"
     if D.dist is not None:
-        D.barrier()
-        D.dist.destroy_process_group()
-    guard.disarm()
+        D.barrier()  # every rank is through with its measurements ...
+        torch.cuda.synchronize()  # ... and this rank's share of that barrier has left the device before it may go
     note("done")
-    guard.print_once()  # the very last thing this process writes to stdout: nothing (process-group teardown chatter) follows it
+    # The line goes out BEFORE the process group is torn down: whatever the teardown does (it has aborted once in a rehearsal),
+    # the record is on stdout.  Nothing can follow it there -- fd 1 has pointed at stderr since main() began.
+    guard.print_once()
+    if D.dist is not None:
+        try:
+            D.dist.destroy_process_group()
+        except Exception as exc:  # noqa: BLE001
+            print(f"bench.py: destroy_process_group: {type(exc).__name__}: {exc}", file=sys.stderr, flush=True)
+    guard.disarm()
+    if D.dist is not None:
+        # the measurements are done and printed, the process group is shut down: leave without running the interpreter's and the
+        # communication library's static destructors against each other
+        sys.stderr.flush()
+        os._exit(0)
 
 
 if __name__ == "__main__":

@@ -21,6 +21,12 @@ def _strict_loads(s):
 
 
 def _one_json_line(out, rc=0):
+    if out.returncode != rc:  # keep the whole stderr of a run that ended in an unexpected way (gpurun merges gpurun_out/ back)
+        dump = os.path.join(REPO, "gpurun_out")
+        if os.path.isdir(dump):
+            with open(os.path.join(dump, f"bench_contract_failure_rc{out.returncode}.err"), "w") as f:
+                f.write(out.stderr)
+                f.write("\n---- stdout ----\n" + out.stdout)
     assert out.returncode == rc, (out.returncode, out.stderr[-3000:])
     lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, f"stdout must carry exactly one line, got {len(lines)}: {out.stdout[:500]}"

@@ -185,3 +185,18 @@ def test_strict_names_what_it_nulled():
     out = b.strict({"a": float("nan"), "b": [1.0, float("-inf")], "c": {"d": 2}}, bad)
     assert out == {"a": None, "b": [1.0, None], "c": {"d": 2}} and bad == ["a", "b[1]"]
     json.dumps(out, allow_nan=False)
+
+
+def test_the_counter_pass_child_in_flight_is_ended_by_its_own_process_group():
+    """The watchdog (and a counter pass's own timeout) must not leave a rocprofv3 child behind on the GPU: bench.kill_child() ends the
+    process group it started -- by that group's id, nothing else -- and reaps it."""
+    b = _bench()
+    proc = subprocess.Popen([sys.executable, "-c", "import subprocess, sys, time; subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(120)']); time.sleep(120)"],
+                            start_new_session=True)
+    time.sleep(0.5)
+    b._CHILD[0] = proc
+    t0 = time.perf_counter()
+    b.kill_child()
+    assert proc.poll() is not None and time.perf_counter() - t0 < 10
+    b._CHILD[0] = None
+    b.kill_child()  # nothing in flight: a no-op
