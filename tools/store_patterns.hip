@@ -90,6 +90,45 @@ __global__ __launch_bounds__(256) void k_tiled(u4 *buf, size_t n16, int tile16, 
     }
 }
 
+// (4) the tiled persistent walk with the number of stores a wavefront may have in flight bounded: after each 1-KiB store instruction
+// the wave waits until at most `KEEP` of its stores are unacknowledged (s_waitcnt vmcnt: stores count there on gfx9)
+template <int KEEP>
+__global__ __launch_bounds__(256) void k_tiled_throttled(u4 *buf, size_t n16, int tile16, int chunk16) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const u4 v = {1u, 2u, 3u, (unsigned)blockIdx.x};
+    const size_t tiles = (n16 + tile16 - 1) / tile16;
+    for (size_t t = blockIdx.x; t < tiles; t += gridDim.x) {
+        const size_t tb = t * tile16;
+        for (int c = wave * chunk16; c < tile16; c += 4 * chunk16)
+            for (int i = lane; i < chunk16; i += 64) {
+                if (tb + c + i < n16 && c + i < tile16) buf[tb + c + i] = v;
+                if (KEEP == 0) __builtin_amdgcn_s_waitcnt(0x0F70 | 0);       // vmcnt(0) (expcnt / lgkmcnt fields left at "no wait")
+                else if (KEEP == 1) __builtin_amdgcn_s_waitcnt(0x0F70 | 1);
+                else if (KEEP == 2) __builtin_amdgcn_s_waitcnt(0x0F70 | 2);
+                else if (KEEP == 4) __builtin_amdgcn_s_waitcnt(0x0F70 | 4);
+                else if (KEEP == 8) __builtin_amdgcn_s_waitcnt(0x0F70 | 8);
+            }
+    }
+}
+
+// (5) persistent workgroups that draw their next chunk from ONE global ticket counter: chunks go out in address order whatever the
+// workgroups' speeds are, as with the hardware's own dispatch of a huge grid -- the front stays tight
+__global__ __launch_bounds__(256) void k_ticket(u4 *buf, size_t n16, int chunk16, unsigned *ticket) {
+    __shared__ unsigned s_t;
+    const u4 v = {1u, 2u, 3u, (unsigned)blockIdx.x};
+    const size_t chunks = (n16 + chunk16 - 1) / chunk16;
+    for (;;) {
+        if (threadIdx.x == 0) s_t = atomicAdd(ticket, 1u);
+        __syncthreads();
+        const size_t c = s_t;
+        __syncthreads();
+        if (c >= chunks) break;
+        const size_t base = c * chunk16;
+        for (int i = threadIdx.x; i < chunk16; i += 256)
+            if (base + i < n16) buf[base + i] = v;
+    }
+}
+
 struct Res {
     const char *name;
     double tbps;
@@ -171,6 +210,32 @@ int main(int argc, char **argv) {
         printf("TILED persistent, tile 1228800 B, wave chunk %6d B        %5.2f TB/s   nt %5.2f\n", chunk,
                timeit([&] { hipLaunchKernelGGL(k_tiled<false>, dim3(1536), dim3(256), 0, 0, buf, n16, 1228800 / 16, chunk / 16); }, bytes),
                timeit([&] { hipLaunchKernelGGL(k_tiled<true>, dim3(1536), dim3(256), 0, 0, buf, n16, 1228800 / 16, chunk / 16); }, bytes));
+    for (unsigned grid : {1536u, 2048u}) {
+        printf("TILED persistent, tile 1228800 B, 5 KiB chunks, grid %u, stores in flight per wave <= 0+1 / 1+1 / 2+1 / 4+1 / 8+1:  %5.2f  %5.2f  %5.2f  %5.2f  %5.2f TB/s\n", grid,
+               timeit([&] { hipLaunchKernelGGL(k_tiled_throttled<0>, dim3(grid), dim3(256), 0, 0, buf, n16, 1228800 / 16, 320); }, bytes),
+               timeit([&] { hipLaunchKernelGGL(k_tiled_throttled<1>, dim3(grid), dim3(256), 0, 0, buf, n16, 1228800 / 16, 320); }, bytes),
+               timeit([&] { hipLaunchKernelGGL(k_tiled_throttled<2>, dim3(grid), dim3(256), 0, 0, buf, n16, 1228800 / 16, 320); }, bytes),
+               timeit([&] { hipLaunchKernelGGL(k_tiled_throttled<4>, dim3(grid), dim3(256), 0, 0, buf, n16, 1228800 / 16, 320); }, bytes),
+               timeit([&] { hipLaunchKernelGGL(k_tiled_throttled<8>, dim3(grid), dim3(256), 0, 0, buf, n16, 1228800 / 16, 320); }, bytes));
+    }
+    for (unsigned grid : {256u, 512u, 768u, 1024u})
+        printf("TILED persistent, tile 1228800 B, 5 KiB chunks, grid %4u (fewer wavefronts), unthrottled / <= 1 / <= 3 in flight:  %5.2f  %5.2f  %5.2f TB/s\n", grid,
+               timeit([&] { hipLaunchKernelGGL(k_tiled<false>, dim3(grid), dim3(256), 0, 0, buf, n16, 1228800 / 16, 320); }, bytes),
+               timeit([&] { hipLaunchKernelGGL(k_tiled_throttled<0>, dim3(grid), dim3(256), 0, 0, buf, n16, 1228800 / 16, 320); }, bytes),
+               timeit([&] { hipLaunchKernelGGL(k_tiled_throttled<2>, dim3(grid), dim3(256), 0, 0, buf, n16, 1228800 / 16, 320); }, bytes));
+    {
+        unsigned *ticket;
+        CHECK(hipMalloc(&ticket, 4));
+        for (int chunk : {4096, 16384, 65536, 262144, 1228800})
+            for (unsigned grid : {1536u, 2048u}) {
+                printf("persistent, chunks of %7d B drawn from ONE ticket counter, grid %u:   %5.2f TB/s\n", chunk, grid,
+                       timeit([&] {
+                           CHECK(hipMemsetAsync(ticket, 0, 4, 0));
+                           hipLaunchKernelGGL(k_ticket, dim3(grid), dim3(256), 0, 0, buf, n16, chunk / 16, ticket);
+                       }, bytes));
+            }
+        CHECK(hipFree(ticket));
+    }
     CHECK(hipFree(buf));
     return 0;
 }
