@@ -568,6 +568,7 @@ class TimeSeriesEnv:
         if old.get("_handle") is not None:
             self._lib.fe_env_destroy(old["_handle"])
         self.flag_timeout_s = old["flag_timeout_s"]
+        self.obs_audition = None  # (what an earlier audition measured described the old ring)
         if not self.evaluate and self.redraw == "device":
             self._counters[1] = redraw_counter  # the Philox stream goes on where it was
 

@@ -51,6 +51,7 @@ class GraphedRollout:
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
+        env._sync_public_views()  # (pending in-place edits of handed-out views are applied now, not frozen into the graph as a copy)
         with torch.cuda.graph(self.graph):
             self._iterate(record=True)
         # what the graph froze: the kernel env.step dispatched to (f32 or promoted share arithmetic) and the pointers of the
