@@ -52,7 +52,12 @@ class GraphedRollout:
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
         env._sync_public_views()  # (pending in-place edits of handed-out views are applied now, not frozen into the graph as a copy)
-        with torch.cuda.graph(self.graph):
+        # THREAD-LOCAL capture mode: only this thread's calls are held to the capture rules.  In a torch.distributed (RCCL) job the
+        # process group's watchdog thread polls its collectives' events (hipEventQuery) all the time; under the default GLOBAL mode
+        # such a query from another thread while this one captures fails with "operation not permitted when stream is capturing",
+        # the watchdog rethrows and std::terminate()s the process -- seen in one of ~10 rehearsals of bench.py's N > 1 path
+        # (round 6), i.e. whenever a poll happened to fall into a capture.  Everything captured here is issued by this thread.
+        with torch.cuda.graph(self.graph, capture_error_mode="thread_local"):
             self._iterate(record=True)
         # what the graph froze: the kernel env.step dispatched to (f32 or promoted share arithmetic) and the pointers of the
         # env's bound state -- run() refuses to replay once either has changed

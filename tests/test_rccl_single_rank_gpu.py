@@ -71,3 +71,52 @@ def test_trajectory_all_gather_through_rccl_one_rank(tmp_path):
     out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-4000:]
     assert "RCCL single-rank all-gather ok" in out.stdout
+
+
+CAPTURE_WORKER = r'''
+import os, sys, time
+import torch
+import torch.distributed as dist
+sys.path.insert(0, os.environ["FE_REPO"])
+import finenvs_amd
+from finenvs_amd.data import synthetic
+from finenvs_amd.rollout import GraphedRollout
+
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+N, A, W, K = 2048, 1, 8, 8
+prices, day_id, _ = synthetic.synthetic_series(6, A, 60, 1234)
+env = finenvs_amd.TimeSeriesEnv(prices=prices, day_id=day_id, num_intervals=W, num_envs=N, redraw="device", seed=3, obs_buffers=2)
+acts = [(torch.rand((N, A), device="cuda") * 2 - 1) for _ in range(K)]
+x = torch.ones((4,), device="cuda")
+t0 = time.perf_counter()
+captures = 0
+# A collective leaves work for the process group's watchdog thread to poll (an event query every ~100 ms until it has seen the work
+# complete); graph captures go on meanwhile for more than a second: some poll falls into some capture.
+while time.perf_counter() - t0 < 1.5:
+    dist.all_reduce(x, async_op=True)
+    roll = GraphedRollout(env, lambda obs, k: acts[k], K, warmup=0)
+    roll.run()
+    captures += 1
+torch.cuda.synchronize()
+dist.destroy_process_group()
+print(f"captured {captures} graphs beside a polling RCCL watchdog: ok")
+'''
+
+
+def test_graph_capture_beside_the_process_groups_watchdog_thread(tmp_path):
+    """GraphedRollout captures in THREAD-LOCAL mode.  ProcessGroupNCCL's watchdog thread polls its collectives' events from another
+    thread; under torch's default global capture mode such a poll during a capture fails with "operation not permitted when stream
+    is capturing", the watchdog rethrows and the process is std::terminate()d -- which is how one of ~10 rehearsals of bench.py's
+    N > 1 path died in round 6 (exit code -6, after the headline, before its line).  Collectives and captures interleaved for 1.5 s
+    reproduce the collision; with the thread-local mode the worker must come through."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    script = tmp_path / "capture_worker.py"
+    script.write_text(CAPTURE_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0",
+               FE_REPO=os.path.dirname(os.path.dirname(os.path.abspath(__file__))), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    out = subprocess.run([sys.executable, str(script)], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout[-1000:] + out.stderr[-4000:])
+    assert "beside a polling RCCL watchdog: ok" in out.stdout
