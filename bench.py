@@ -36,7 +36,6 @@ import statistics
 import sys
 import time
 
-import numpy as np
 import torch
 
 REPO = os.path.dirname(os.path.abspath(__file__))
