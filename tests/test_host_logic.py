@@ -307,3 +307,36 @@ def test_host_flag_poll_backs_off_and_rereads_after_the_timeout_synchronise():
     with pytest.raises(HostFlagTimeout, match="0x4"):
         poll_host_word(lambda: 4, lambda v: v >> 1 == seq, 0.5, on_timeout=lambda: calls.append(1), spin=3, clock=c.now, sleep=c.sleep)
     assert calls == [1]
+
+
+def test_bench_legs_module_imports_against_the_running_bench_module():
+    """tools/bench_legs.py is imported by bench.py only after the headline is in hand, inside try / except blocks under the watchdog:
+    a NameError or a missing re-export there would not fail the run, it would silently turn every extra leg into an `error` entry.
+    So: import it here the way bench.py does (`bench` registered in sys.modules first) and check the entry points exist."""
+    import importlib.util
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    saved = sys.modules.get("bench")
+    sys.modules["bench"] = bench
+    try:
+        spec.loader.exec_module(bench)
+        spec2 = importlib.util.spec_from_file_location("bench_legs_under_test", os.path.join(root, "tools", "bench_legs.py"))
+        legs = importlib.util.module_from_spec(spec2)
+        spec2.loader.exec_module(legs)
+    finally:
+        if saved is None:
+            sys.modules.pop("bench", None)
+        else:
+            sys.modules["bench"] = saved
+    for name in ("two_stream_leg", "reference_semantics_leg", "strong_scaling_leg", "device_guard_check", "fused_rollout_legs"):
+        assert callable(getattr(legs, name)), name
+    assert legs.CONFIGS is bench.CONFIGS and legs.KernelTrain is bench.KernelTrain  # the running module's objects, not a second copy
+    # every name the legs use from bench exists there (a rename in bench.py must not leave the legs behind)
+    import ast
+
+    tree = ast.parse(open(os.path.join(root, "tools", "bench_legs.py")).read())
+    imported = [a.name for node in ast.walk(tree) if isinstance(node, ast.ImportFrom) and node.module == "bench" for a in node.names]
+    assert imported and all(hasattr(bench, n) for n in imported), imported
