@@ -199,3 +199,19 @@ def test_the_counter_pass_child_in_flight_is_ended_by_its_own_process_group():
     assert proc.poll() is not None and time.perf_counter() - t0 < 10
     b._CHILD[0] = None
     b.kill_child()  # nothing in flight: a no-op
+
+
+def test_a_failed_counter_pass_is_described_by_the_childs_own_words(tmp_path):
+    """`traffic_live_error` carries the child's last informative stderr line (round 5 threw the stderr away and reported "exited with
+    1"): a Python traceback's last line starts with the exception's name and reason; chatter after it does not hide it."""
+    b = _bench()
+    p = tmp_path / "child.err"
+    p.write_text("/opt/amdgpu/share/libdrm/amdgpu.ids: No such file or directory\n[pmc-child] config 4: 61.2 GiB free, observation ring 1 x 143.1 GiB\n"
+                 "Traceback (most recent call last):\n  File \"bench.py\", line 1, in <module>\n"
+                 "torch.OutOfMemoryError: HIP out of memory. Tried to allocate 143.05 GiB. GPU 0 has a total capacity of 287.98 GiB of which 60.83 GiB is free. " + "x" * 400 + "\n"
+                 "some teardown chatter\n")
+    got = b._last_words(str(p))
+    assert got.startswith("torch.OutOfMemoryError: HIP out of memory. Tried to allocate 143.05 GiB") and len(got) <= 110
+    p.write_text("only chatter\nmore chatter\n")
+    assert b._last_words(str(p)) == "more chatter"
+    assert b._last_words(str(tmp_path / "absent.err")) == ""
