@@ -306,6 +306,22 @@ static int configure_launch(fe_env *env) {
         if (resident > 8) resident -= resident % 8;
     }
     int64_t grid = num_tiles < resident ? num_tiles : resident;
+    if (A > 1) {
+        // Multi-asset envs launch k x the resident workgroup count (k = 8, 4 or 2; every workgroup still walks >= 2 tiles, grid-strided):
+        // the hardware hands the later workgroups out in order as earlier ones retire, so the launch is balanced by dispatch instead of
+        // by a fixed share per persistent workgroup, whose shares of HBM differ by 10x (profiles/r06_microbench/config3_launch_size.md).
+        // Measured (round 6, interleaved on one ring where it fits; table 11 there): k = 8 against k = 1 -- config 4 25.59 -> 24.00 ms
+        // (6.29 -> 6.71 TB/s of observation: torch's fill rate on that buffer), config-5 shard 13.03 -> 12.59 ms, config 3 3.62 -> 3.53 ms;
+        // multiples of the resident count only (4 096 / 8 192 of 1 536 resident: no gain at config 3), and not one tile per
+        // workgroup (k = 64 at config 4: 2 % slower than k = 1).  The tile % 8 = XCD mapping is unchanged (k x resident is a multiple of 8).
+        // Single-asset envs keep the resident grid: there every larger grid measured slower (4 - 57 %, their launch is 28 us).
+        for (int k = 8; k > 1; k >>= 1) {
+            if ((int64_t)k * resident <= num_tiles / 2) {
+                grid = (int64_t)k * resident;
+                break;
+            }
+        }
+    }
     if (env->grid_override > 0) grid = env->grid_override;
     env->grid = (int)grid;
     env->lds = lds_bytes((int)EB, A);
