@@ -63,17 +63,23 @@ def main():
         torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
+        REV = os.environ.get("STAMP_REV") == "1"  # the notify form's walk: tiles from the END of the buffer first (time vs address)
+        dev_flag = torch.zeros((1,), dtype=torch.int64, device=DEV)
         for i in range(K):
             _lib.check(lib.fe_env_bind_stats(h, None, None, C.c_void_p(stamps[i].data_ptr())))
-            _lib.check(lib.fe_env_step_traj(env._handle_v, acts[i % 2].data_ptr(), env._obs_ring[i % 2].data_ptr(), rew.data_ptr(), done.data_ptr(),
-                                            act.data_ptr(), None, None, st))
+            if REV:
+                _lib.check(lib.fe_env_step_traj_notify(env._handle_v, acts[i % 2].data_ptr(), env._obs_ring[i % 2].data_ptr(), rew.data_ptr(), done.data_ptr(),
+                                                       act.data_ptr(), None, None, C.c_void_p(dev_flag.data_ptr()), i + 1, st))
+            else:
+                _lib.check(lib.fe_env_step_traj(env._handle_v, acts[i % 2].data_ptr(), env._obs_ring[i % 2].data_ptr(), rew.data_ptr(), done.data_ptr(),
+                                                act.data_ptr(), None, None, st))
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / K
         B = (40 * W * A + 84 * A + 36) * N
         tile_bytes = (40 * W * A + 84 * A + 36) * info["tile_envs"]
         S = [s.cpu().numpy().astype(np.int64) for s in stamps]
-        print(f"\n## {N} envs x {A} assets x W{W}: grid {grid}, tile {info['tile_envs']} envs, {ms:.3f} ms per launch by HIP events = {B / ms / 1e9 / 8:.3f} of 8 TB/s")
+        print(f"\n## {'REVERSED walk (notify form): ' if os.environ.get('STAMP_REV') == '1' else ''}{N} envs x {A} assets x W{W}: grid {grid}, tile {info['tile_envs']} envs, {ms:.3f} ms per launch by HIP events = {B / ms / 1e9 / 8:.3f} of 8 TB/s")
         for i in (3,):
             s, prev = S[i], S[i - 1]
             stride = int(os.environ.get("STAMP_STRIDE", "1"))  # the build's FE_STAMP_STRIDE: one stamp pair per `stride` tiles
